@@ -1,0 +1,117 @@
+/*
+ * sim_a_splat_amd.h -- C ABI of the MI355X (gfx950) Gaussian-splat rasterizer that sits behind
+ * sim_a_splat's render-image calls.
+ *
+ * The reference reaches its renderer through two Python call sites and has no native FFI of its
+ * own, so every entry point cites the reference call it serves
+ * (paths relative to the reference tree):
+ *
+ *   Door A  GaussianSplat.render(pose) -> pipeline.model.get_outputs_for_camera(cameras, obb_box=None)
+ *           sim_a_splat/ns_utils/nerfstudio_utils.py:123-177 (call at :166-172)
+ *   Door B  client.get_render(height, width, wxyz, position)
+ *           sim_a_splat/env/splat/splat_env_wrapper.py:148-157, sim_a_splat/splat/splat_handler.py:339-344
+ *           scene.add_gaussian_splats(...) registration      sim_a_splat/splat/splat_handler.py:106-141
+ *           handle.wxyz / handle.position updates             sim_a_splat/splat/splat_handler.py:283-288
+ *
+ * Conventions: plain C types only.  `means`, `quats`, ... of sas_scene_upload may be host or
+ * device pointers (copied with hipMemcpyDefault).  Output pointers of sas_render are DEVICE
+ * pointers owned by the caller (e.g. torch tensors' data_ptr()).  viewmat / K / background /
+ * group poses are small HOST arrays.  No exceptions cross the ABI: every call returns 0 or a
+ * negative sas_status and sas_last_error() describes the failure.  One ctx per (device, stream);
+ * calls on one ctx are not re-entrant.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ */
+#ifndef SIM_A_SPLAT_AMD_H
+#define SIM_A_SPLAT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sas_ctx sas_ctx;
+
+typedef enum {
+    SAS_OK = 0,
+    SAS_ERR_INVALID = -1,   /* bad argument */
+    SAS_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SAS_ERR_NO_SCENE = -3,  /* render before sas_scene_upload */
+    SAS_ERR_OOM = -4,       /* device allocation failed */
+    SAS_ERR_NO_DEVICE = -5  /* no gfx950 device visible */
+} sas_status;
+
+/* sas_render flags */
+#define SAS_DEPTH_FILL_MAX 1u /* depth = where(alpha > 0, ED, max(ED)): nerfstudio get_outputs (T0) */
+#define SAS_ASYNC 2u          /* enqueue only; results valid after sas_wait() */
+#define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
+#define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
+
+/* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
+enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT, SAS_T_BLEND, SAS_T_TOTAL, SAS_T_COUNT };
+
+/* sas_frame_stats slots (int64) of the last completed frame */
+enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS, SAS_S_COUNT };
+
+/* Create / destroy a rasterizer context on HIP device `device`. */
+int sas_create(int device, sas_ctx **out);
+int sas_destroy(sas_ctx *ctx);
+
+/*
+ * Upload (replace) the scene.  Serves GSplatLoader -> scene registration
+ * (sim_a_splat/splat/splat_utils.py:33-45, splat_handler.py:106-141).
+ *   means      [n,3]   world positions
+ *   quats      [n,4]   wxyz, any norm   } Door A form (gsplat normalises), or both NULL and
+ *   scales     [n,3]   exp() applied    }
+ *   cov6       [n,6]   xx xy xz yy yz zz  Door B form (viser takes 3x3 covariances)
+ *   opacities  [n]     sigmoid() applied
+ *   colors     sh_degree >= 0: [n,(sh_degree+1)^2,3] SH coefficients (features_dc ++ features_rest)
+ *              sh_degree <  0: [n,3] final RGB in 0..1 (Door B: SH2RGB already applied)
+ *   group_id   [n] uint8 splat-group index, or NULL (single static group)
+ *   n_groups   number of groups (<= 256); poses start as identity
+ */
+int sas_scene_upload(sas_ctx *ctx, int64_t n, const float *means, const float *quats, const float *scales,
+                     const float *cov6, const float *opacities, const float *colors, int sh_degree,
+                     const uint8_t *group_id, int n_groups);
+
+/* Per-group rigid poses, [n_groups,12] row-major (R|t), host pointer.  Serves the per-step
+ * `splat_links_handler[i].wxyz/.position = ...` assignments (splat_handler.py:283-288). */
+int sas_set_group_poses(sas_ctx *ctx, int n_groups, const float *Rt);
+
+/*
+ * Render one view.  Serves get_outputs_for_camera (Door A) and get_render (Door B).
+ *   viewmat     [16] row-major world->camera, OpenCV axes (+z forward)
+ *   K           [9]  row-major intrinsics
+ *   background  [3]
+ *   rgb   [H,W,3] f32 or NULL     clamp(render + (1-alpha)*background, 0, 1)
+ *   alpha [H,W]   f32 or NULL     accumulation
+ *   depth [H,W]   f32 or NULL     expected depth (see SAS_DEPTH_FILL_MAX)
+ *   rgb8  [H,W,3] u8  or NULL     floor(rgb*255 + 0.5)
+ *   stream      hipStream_t (NULL = default stream)
+ * Without SAS_ASYNC the call returns after the frame is complete.
+ */
+int sas_render(sas_ctx *ctx, const float *viewmat, const float *K, int width, int height,
+               const float *background, unsigned flags, float *rgb, float *alpha, float *depth,
+               uint8_t *rgb8, void *stream);
+
+/* Complete the last SAS_ASYNC frame: synchronise, and if the intersection buffer overflowed,
+ * grow it and render the frame again. */
+int sas_wait(sas_ctx *ctx);
+
+const char *sas_last_error(sas_ctx *ctx);
+int sas_stage_times(sas_ctx *ctx, float *ms, int n);
+int sas_frame_stats(sas_ctx *ctx, int64_t *stats, int n);
+
+/* Parity hooks (HOST output pointers, any may be NULL): per-Gaussian projection results and the
+ * per-tile sorted lists of the last completed frame, in the layout of gsplat's intermediate
+ * tensors (radii [n,2] i32, means2d [n,2], depths [n], conics [n,3], colors [n,3];
+ * tile_offsets [tiles+1] i32, sorted_ids [<=cap] i32). */
+int sas_read_projection(sas_ctx *ctx, int32_t *radii, float *means2d, float *depths, float *conics,
+                        float *colors);
+int sas_read_tile_lists(sas_ctx *ctx, int32_t *tile_offsets, int32_t *sorted_ids, int64_t cap);
+
+const char *sas_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIM_A_SPLAT_AMD_H */

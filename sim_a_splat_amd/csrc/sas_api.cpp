@@ -1,0 +1,461 @@
+// sas_api.cpp -- context management and the C ABI declared in include/sim_a_splat_amd.h.
+// Compiled by hipcc together with sas_kernels.hip into libsas_hip.so.  Host float arithmetic
+// that feeds the kernels (camera constants) follows the arithmetic contract: built with
+// -ffp-contract=off, fused only where fmaf() is written.
+#include "../../include/sim_a_splat_amd.h"
+#include "sas_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct RenderArgs {
+    float viewmat[16], K[9], bg[3];
+    int W = 0, H = 0;
+    unsigned flags = 0;
+    float *rgb = nullptr, *alpha = nullptr, *depth = nullptr;
+    uint8_t *rgb8 = nullptr;
+    hipStream_t stream = nullptr;
+    bool valid = false;
+};
+
+}  // namespace
+
+struct sas_ctx {
+    int device = 0;
+    std::string err;
+    // scene
+    DevBuf g0, g1, g2, col, groups;
+    SasScene scene{};
+    bool has_scene = false;
+    std::vector<float> group_host;
+    // frame scratch
+    DevBuf rec, info, tilebuf, keys, ids, counters;
+    long long cap = 0;
+    int tiles_alloc = 0;
+    unsigned *stats_host = nullptr;  // pinned, 8 words
+    // last frame
+    RenderArgs last;
+    SasCam cam{};
+    bool pending = false;
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0};
+    int64_t regrows = 0;
+    hipEvent_t ev[SAS_T_COUNT + 1] = {};
+    bool ev_made = false, ev_valid = false;
+    float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(sas_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? SAS_ERR_OOM : SAS_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+int ensure(sas_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.p) return SAS_OK;
+    if (b.p) {
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return SAS_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// Camera constants in the oracle's operation order (oracle/sas_oracle.c cam_from, project_one).
+void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
+{
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = V[4 * i + j];
+        c.t[i] = V[4 * i + 3];
+    }
+    for (int i = 0; i < 3; ++i) {
+        float d = fmaf(c.R[6 + i], c.t[2], fmaf(c.R[3 + i], c.t[1], c.R[0 + i] * c.t[0]));
+        c.campos[i] = -d;
+    }
+    c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+    c.W = W; c.H = H;
+    c.tw = (W + SAS_TILE - 1) / SAS_TILE;
+    c.th = (H + SAS_TILE - 1) / SAS_TILE;
+    c.Wf = (float)W; c.Hf = (float)H;
+    const float tan_fovx = (0.5f * c.Wf) / c.fx;
+    const float tan_fovy = (0.5f * c.Hf) / c.fy;
+    c.lim_x_pos = fmaf(0.3f, tan_fovx, (c.Wf - c.cx) / c.fx);
+    c.lim_x_neg = fmaf(0.3f, tan_fovx, c.cx / c.fx);
+    c.lim_y_pos = fmaf(0.3f, tan_fovy, (c.Hf - c.cy) / c.fy);
+    c.lim_y_neg = fmaf(0.3f, tan_fovy, c.cy / c.fy);
+}
+
+SasFrame frame_of(sas_ctx *c, int tiles)
+{
+    SasFrame f{};
+    f.rec = (float4 *)c->rec.p;
+    f.info = (uint4 *)c->info.p;
+    // counters block: [stats 8 words][tile_count tiles+1]   (zeroed every frame by one memset)
+    f.stats = (unsigned *)c->counters.p;
+    f.tile_count = (int *)c->counters.p + 8;
+    f.tile_offset = (int *)c->tilebuf.p;
+    f.tile_cursor = (int *)c->tilebuf.p + (tiles + 1);
+    f.keys = (unsigned long long *)c->keys.p;
+    f.sorted_ids = (int *)c->ids.p;
+    f.cap = c->cap;
+    return f;
+}
+
+int enqueue_frame(sas_ctx *c)
+{
+    const RenderArgs &a = c->last;
+    make_cam(a.viewmat, a.K, a.W, a.H, c->cam);
+    const SasCam &cam = c->cam;
+    const int tiles = cam.tw * cam.th;
+    const int64_t n = c->scene.n;
+    int rc;
+    if ((rc = ensure(c, c->rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, c->info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, c->tilebuf, sizeof(int) * (size_t)(2 * tiles + 2)))) return rc;
+    size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
+    cbytes = (cbytes + 15) & ~(size_t)15;
+    if ((rc = ensure(c, c->counters, cbytes))) return rc;
+    if (c->cap == 0) {
+        long long want = 4 * (long long)n;
+        if (want < (1ll << 20)) want = 1ll << 20;
+        c->cap = want;
+    }
+    if ((rc = ensure(c, c->keys, sizeof(unsigned long long) * (size_t)c->cap))) return rc;
+    if ((rc = ensure(c, c->ids, sizeof(int) * (size_t)c->cap))) return rc;
+
+    hipStream_t st = a.stream;
+    const bool timing = (a.flags & SAS_TIMING) != 0;
+    if (timing && !c->ev_made) {
+        for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+        c->ev_made = true;
+    }
+    SasFrame f = frame_of(c, tiles);
+    SasOutputs o{};
+    o.rgb = a.rgb; o.alpha = a.alpha; o.depth = a.depth; o.rgb8 = a.rgb8;
+    o.bg[0] = a.bg[0]; o.bg[1] = a.bg[1]; o.bg[2] = a.bg[2];
+
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, cbytes, st));
+    sas_launch_project(st, c->scene, cam, f);
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    sas_launch_scan(st, cam, f);
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    sas_launch_scatter(st, c->scene, cam, f);
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    sas_launch_sort(st, cam, f);
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0);
+    if (a.depth && (a.flags & SAS_DEPTH_FILL_MAX)) sas_launch_depth_fill(st, cam, f, a.depth);
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    c->ev_valid = timing;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->stats_host, c->counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    c->pending = true;
+    return SAS_OK;
+}
+
+int finish_frame(sas_ctx *c)
+{
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(c, hipStreamSynchronize(c->last.stream));
+        c->pending = false;
+        const unsigned *s = c->stats_host;
+        c->stats[SAS_S_NVISIBLE] = s[0];
+        c->stats[SAS_S_NISECT] = s[1];
+        c->stats[SAS_S_MAX_TILE_LEN] = s[4];
+        c->stats[SAS_S_CAPACITY] = c->cap;
+        c->stats[SAS_S_REGROWS] = c->regrows;
+        if (c->ev_valid) {
+            for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], c->ev[k], c->ev[k + 1]);
+            (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], c->ev[0], c->ev[5]);
+        }
+        if (!s[2]) return SAS_OK;
+        // intersection buffer too small: grow to the measured need (+25 %) and render again
+        long long need = (long long)s[1];
+        c->cap = need + need / 4 + 1024;
+        c->regrows++;
+        int rc = enqueue_frame(c);
+        if (rc) return rc;
+    }
+    return fail(c, SAS_ERR_HIP, "intersection buffer kept overflowing");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sas_version(void) { return "sim_a_splat_amd 0.1 (gfx950)"; }
+
+int sas_create(int device, sas_ctx **out)
+{
+    if (!out) return SAS_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SAS_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SAS_ERR_INVALID;
+    sas_ctx *c = new (std::nothrow) sas_ctx();
+    if (!c) return SAS_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&c->stats_host, 8 * sizeof(unsigned)) != hipSuccess) {
+        delete c;
+        return SAS_ERR_HIP;
+    }
+    memset(c->stats_host, 0, 8 * sizeof(unsigned));
+    *out = c;
+    return SAS_OK;
+}
+
+int sas_destroy(sas_ctx *c)
+{
+    if (!c) return SAS_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->pending) (void)hipStreamSynchronize(c->last.stream);
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
+                      &c->counters})
+        release(*b);
+    if (c->stats_host) (void)hipHostFree(c->stats_host);
+    if (c->ev_made)
+        for (auto &e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+    return SAS_OK;
+}
+
+const char *sas_last_error(sas_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *quats, const float *scales,
+                     const float *cov6, const float *opacities, const float *colors, int sh_degree,
+                     const uint8_t *group_id, int n_groups)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (n < 0 || n > 0x7fffffffll) return fail(c, SAS_ERR_INVALID, "n=%lld out of range", (long long)n);
+    if (sh_degree > 3) return fail(c, SAS_ERR_INVALID, "sh_degree %d > 3", sh_degree);
+    if (n > 0 && (!means || !opacities || !colors)) return fail(c, SAS_ERR_INVALID, "means/opacities/colors required");
+    const bool quat_mode = quats && scales;
+    if (n > 0 && !quat_mode && !cov6) return fail(c, SAS_ERR_INVALID, "need quats+scales or cov6");
+    if (n_groups < 0 || n_groups > 256) return fail(c, SAS_ERR_INVALID, "n_groups %d out of [0,256]", n_groups);
+    if (group_id && n_groups <= 0) return fail(c, SAS_ERR_INVALID, "group_id given but n_groups == 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) HIP_TRY(c, hipStreamSynchronize(c->last.stream));
+    c->pending = false;
+    c->has_scene = false;
+
+    const int deg = sh_degree < 0 ? -1 : sh_degree;
+    const int coeff_floats = deg < 0 ? 3 : 3 * (deg + 1) * (deg + 1);
+    const int planes = (coeff_floats + 3) / 4;
+    const int64_t n_pad = (n + 63) & ~63ll;
+    int rc;
+    const size_t np = (size_t)(n_pad > 0 ? n_pad : 64);
+    if ((rc = ensure(c, c->g0, sizeof(float4) * np))) return rc;
+    if ((rc = ensure(c, c->g1, sizeof(float4) * np))) return rc;
+    if ((rc = ensure(c, c->g2, sizeof(float4) * np))) return rc;
+    if ((rc = ensure(c, c->col, sizeof(float4) * np * planes))) return rc;
+
+    if (n > 0) {
+        // stage the caller's arrays (host or device) and re-lay them out on the device
+        DevBuf s_means, s_q, s_s, s_cov, s_op, s_col, s_gid;
+        auto stage = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+            int r = ensure(c, b, bytes);
+            if (r) return r;
+            HIP_TRY(c, hipMemcpy(b.p, src, bytes, hipMemcpyDefault));
+            return SAS_OK;
+        };
+        rc = stage(s_means, means, sizeof(float) * 3 * n);
+        if (!rc && quat_mode) rc = stage(s_q, quats, sizeof(float) * 4 * n);
+        if (!rc && quat_mode) rc = stage(s_s, scales, sizeof(float) * 3 * n);
+        if (!rc && !quat_mode) rc = stage(s_cov, cov6, sizeof(float) * 6 * n);
+        if (!rc) rc = stage(s_op, opacities, sizeof(float) * n);
+        if (!rc) rc = stage(s_col, colors, sizeof(float) * (size_t)coeff_floats * n);
+        if (!rc && group_id) rc = stage(s_gid, group_id, (size_t)n);
+        if (!rc) {
+            sas_launch_relayout(nullptr, n, n_pad, (const float *)s_means.p, (const float *)s_q.p, (const float *)s_s.p,
+                                (const float *)s_cov.p, (const float *)s_op.p, (const float *)s_col.p, coeff_floats,
+                                planes, (const uint8_t *)s_gid.p, (float4 *)c->g0.p, (float4 *)c->g1.p,
+                                (float4 *)c->g2.p, (float4 *)c->col.p);
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = fail(c, SAS_ERR_HIP, "relayout: %s", hipGetErrorString(e));
+        }
+        for (DevBuf *b : {&s_means, &s_q, &s_s, &s_cov, &s_op, &s_col, &s_gid}) release(*b);
+        if (rc) return rc;
+    }
+
+    c->scene = SasScene{};
+    c->scene.g0 = (const float4 *)c->g0.p;
+    c->scene.g1 = (const float4 *)c->g1.p;
+    c->scene.g2 = (const float4 *)c->g2.p;
+    c->scene.col = (const float4 *)c->col.p;
+    c->scene.n = n;
+    c->scene.n_pad = n_pad;
+    c->scene.sh_degree = deg;
+    c->scene.cov_mode = quat_mode ? 0 : 1;
+    c->scene.n_groups = group_id ? n_groups : 0;
+    c->scene.group_Rt = nullptr;
+    c->group_host.clear();
+    if (group_id) {
+        c->group_host.assign((size_t)12 * n_groups, 0.0f);
+        for (int g = 0; g < n_groups; ++g) c->group_host[12 * g + 0] = c->group_host[12 * g + 5] = c->group_host[12 * g + 10] = 1.0f;
+        if ((rc = ensure(c, c->groups, sizeof(float) * 12 * 256))) return rc;
+        HIP_TRY(c, hipMemcpy(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice));
+        c->scene.group_Rt = (const float *)c->groups.p;
+    }
+    c->cap = 0;  // re-derive the intersection capacity for the new scene
+    c->has_scene = true;
+    return SAS_OK;
+}
+
+int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
+{
+    if (!c || !Rt) return SAS_ERR_INVALID;
+    if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
+    if (n_groups != c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "scene has %d groups, got %d", c->scene.n_groups, n_groups);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) {
+        int rc = finish_frame(c);
+        if (rc) return rc;
+    }
+    c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
+    // stream-ordered behind earlier frames of the same stream; the host copy is ours
+    HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice,
+                              c->last.valid ? c->last.stream : nullptr));
+    return SAS_OK;
+}
+
+int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
+               unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, void *stream)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "sas_render before sas_scene_upload");
+    if (!viewmat || !K) return fail(c, SAS_ERR_INVALID, "viewmat and K are required");
+    if (width <= 0 || height <= 0 || width > 65535 * SAS_TILE || height > 65535 * SAS_TILE)
+        return fail(c, SAS_ERR_INVALID, "bad image size %dx%d", width, height);
+    if (!(K[0] > 0.0f) || !(K[4] > 0.0f)) return fail(c, SAS_ERR_INVALID, "focal lengths must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) {
+        int rc = finish_frame(c);
+        if (rc) return rc;
+    }
+    RenderArgs &a = c->last;
+    memcpy(a.viewmat, viewmat, sizeof(a.viewmat));
+    memcpy(a.K, K, sizeof(a.K));
+    for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
+    a.W = width; a.H = height; a.flags = flags;
+    a.rgb = rgb; a.alpha = alpha; a.depth = depth; a.rgb8 = rgb8;
+    a.stream = (hipStream_t)stream;
+    a.valid = true;
+    int rc = enqueue_frame(c);
+    if (rc) return rc;
+    if (flags & SAS_ASYNC) return SAS_OK;
+    return finish_frame(c);
+}
+
+int sas_wait(sas_ctx *c)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->pending) return SAS_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return finish_frame(c);
+}
+
+int sas_stage_times(sas_ctx *c, float *ms, int n)
+{
+    if (!c || !ms) return SAS_ERR_INVALID;
+    for (int k = 0; k < n && k < SAS_T_COUNT; ++k) ms[k] = c->stage_ms[k];
+    return SAS_OK;
+}
+
+int sas_frame_stats(sas_ctx *c, int64_t *stats, int n)
+{
+    if (!c || !stats) return SAS_ERR_INVALID;
+    for (int k = 0; k < n && k < SAS_S_COUNT; ++k) stats[k] = c->stats[k];
+    return SAS_OK;
+}
+
+int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depths, float *conics, float *colors)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) {
+        int rc = finish_frame(c);
+        if (rc) return rc;
+    }
+    const int64_t n = c->scene.n;
+    std::vector<float> rec((size_t)12 * n);
+    std::vector<uint32_t> info((size_t)4 * n);
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpy(rec.data(), c->rec.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(info.data(), c->info.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost));
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t rr = info[4 * i + 3];
+        const bool vis = rr != 0;
+        const float *r = &rec[12 * i];
+        if (radii) { radii[2 * i] = vis ? (int32_t)(rr & 0xffff) : 0; radii[2 * i + 1] = vis ? (int32_t)(rr >> 16) : 0; }
+        if (means2d) { means2d[2 * i] = vis ? r[0] : 0.f; means2d[2 * i + 1] = vis ? r[1] : 0.f; }
+        if (depths) depths[i] = vis ? r[7] : 0.f;
+        if (conics) { conics[3 * i] = vis ? r[2] : 0.f; conics[3 * i + 1] = vis ? r[3] : 0.f; conics[3 * i + 2] = vis ? r[4] : 0.f; }
+        if (colors) { colors[3 * i] = vis ? r[8] : 0.f; colors[3 * i + 1] = vis ? r[9] : 0.f; colors[3 * i + 2] = vis ? r[10] : 0.f; }
+    }
+    return SAS_OK;
+}
+
+int sas_read_tile_lists(sas_ctx *c, int32_t *tile_offsets, int32_t *sorted_ids, int64_t cap)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) {
+        int rc = finish_frame(c);
+        if (rc) return rc;
+    }
+    const int tiles = c->cam.tw * c->cam.th;
+    if (tile_offsets)
+        HIP_TRY(c, hipMemcpy(tile_offsets, c->tilebuf.p, sizeof(int) * (size_t)(tiles + 1), hipMemcpyDeviceToHost));
+    if (sorted_ids) {
+        int64_t m = c->stats[SAS_S_NISECT];
+        if (m > cap) m = cap;
+        if (m > c->cap) m = c->cap;
+        if (m > 0) HIP_TRY(c, hipMemcpy(sorted_ids, c->ids.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+    }
+    return SAS_OK;
+}
+
+}  // extern "C"

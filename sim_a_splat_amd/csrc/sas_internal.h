@@ -1,0 +1,69 @@
+// Shared between sas_kernels.hip (device code + launchers) and sas_api.cpp (context, C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SAS_TILE 16
+#define SAS_SORT_LDS_CAP 4096  // keys sorted inside LDS by one workgroup (32 KiB)
+
+// Per-frame camera constants, computed on the host with the same f32 operations the oracle uses.
+struct SasCam {
+    float R[9], t[3];
+    float campos[3];
+    float fx, fy, cx, cy;
+    float lim_x_pos, lim_x_neg, lim_y_pos, lim_y_neg;
+    float Wf, Hf;
+    int W, H, tw, th;
+};
+
+// Scene in HBM, re-laid out at upload into 16-byte planes so that lane i of a wave reads
+// bytes [16 i, 16 i + 16) of every plane: each wave-instruction is one contiguous 1 KiB.
+//   g0[n] = (mean.x, mean.y, mean.z, opacity)
+//   g1[n] = quat wxyz                     | cov xx xy xz yy
+//   g2[n] = (scale.x, scale.y, scale.z, group id bits) | (cov yz, cov zz, 0, group id bits)
+//   col[p*n_pad + n] = floats 4p..4p+3 of the Gaussian's flattened [K,3] coefficient block
+struct SasScene {
+    const float4 *g0, *g1, *g2, *col;
+    const float *group_Rt;  // [n_groups,12] or nullptr
+    int64_t n;
+    int64_t n_pad;     // plane stride
+    int sh_degree;     // -1: col plane 0 holds final rgb
+    int cov_mode;      // 1: g1/g2 hold a covariance
+    int n_groups;
+};
+
+// Per-frame scratch owned by the context.
+//   rec[3n..3n+2]  projected record of Gaussian n, 48 B:
+//        (mean2d.x, mean2d.y, conic.a, conic.b) (conic.c, opacity, skip_threshold, depth) (r, g, b, -)
+//   info[n]        (x0 | x1<<16, y0 | y1<<16, depth bits, rx | ry<<16): tile rectangle, 0 if culled
+//   stats          [0] n_visible [1] n_isect [2] overflow [3] max ED bits [4] max tile length
+struct SasFrame {
+    float4 *rec;
+    uint4 *info;
+    int *tile_count;   // [tiles+1]
+    int *tile_offset;  // [tiles+1]
+    int *tile_cursor;  // [tiles]
+    unsigned long long *keys;  // [cap]  depth bits << 32 | gaussian index
+    int *sorted_ids;           // [cap]
+    long long cap;
+    unsigned *stats;           // [8]
+};
+
+struct SasOutputs {
+    float *rgb, *alpha, *depth;
+    uint8_t *rgb8;
+    float bg[3];
+};
+
+// launchers (sas_kernels.hip)
+void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const float *means, const float *quats,
+                         const float *scales, const float *cov6, const float *opac, const float *colors,
+                         int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
+                         float4 *col);
+void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
+void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f);
+void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
+void sas_launch_sort(hipStream_t st, const SasCam &c, const SasFrame &f);
+void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
+                      bool fast_exp);
+void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth);

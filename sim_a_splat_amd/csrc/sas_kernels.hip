@@ -1,0 +1,664 @@
+// sas_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the render-image hot path.
+//
+// Stage map (the algorithm is gsplat 1.5.2's, the decomposition is not):
+//   k_project   T1+T2  one lane per Gaussian: 16-byte plane loads, EWA projection, SH colour,
+//                      48-byte projected record, tile rectangle, per-tile counts
+//   k_scan      T5     exclusive scan of the per-tile counts (tile_offset, scatter cursors)
+//   k_scatter   T3     (depth bits | index) keys into per-tile segments
+//   k_sort      T4     per-tile sort in LDS (replaces the global 64-bit radix sort)
+//   k_blend     T6+T0  one wave per 16x16 tile, 4 pixels per lane, LDS-staged splat queue,
+//                      wave-uniform skip per 8x8 quadrant, front-to-back compositing,
+//                      background / clamp / uint8 / expected-depth epilogue
+//
+// ARITHMETIC CONTRACT: every value that reaches an output is produced by the same
+// sequence of IEEE binary32 operations as oracle/sas_oracle.c -- explicit __builtin_fmaf where
+// the contract fuses, no other contraction (-ffp-contract=off), correctly rounded / and sqrt
+// (hipcc default), polynomial exp/log.  No MFMA: nothing here is a dense contraction.
+#include "sas_internal.h"
+
+#pragma clang fp contract(off)
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+constexpr float kNear = 0.01f, kFar = 1e10f, kEps2d = 0.3f;
+constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
+
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---- contract transcendental functions (mirror sas_oracle_expf / sas_oracle_logf) -------------
+DEV float c_expf(float x)
+{
+    float t = x * 1.4426950408889634f;
+    t = fmaxf(t, -125.0f);
+    t = fminf(t, 126.0f);
+    float n = __builtin_rintf(t);
+    float f = t - n;
+    float p = 0.0013400432653725147f;
+    p = fma_(p, f, 0.009676037356257439f);
+    p = fma_(p, f, 0.05550327152013779f);
+    p = fma_(p, f, 0.2402210682630539f);
+    p = fma_(p, f, 0.6931471824645996f);
+    p = fma_(p, f, 1.0000001192092896f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+DEV float c_logf(float x)
+{
+    unsigned u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.1111111111f;
+    p = fma_(p, s2, 0.1428571429f);
+    p = fma_(p, s2, 0.2f);
+    p = fma_(p, s2, 0.3333333333f);
+    p = fma_(p, s2, 1.0f);
+    float lnm = (2.0f * s) * p;
+    return fma_((float)e, 0.6931471805599453f, lnm);
+}
+
+DEV float affine3(float r0, float r1, float r2, float t, float v0, float v1, float v2)
+{
+    return fma_(r0, v0, fma_(r1, v1, fma_(r2, v2, t)));
+}
+DEV float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    return fma_(a2, b2, fma_(a1, b1, a0 * b0));
+}
+
+// out = R s R^T, s = xx xy xz yy yz zz
+DEV void rot_sym3(const float *R, const float *s, float *out)
+{
+    const float S[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+    float T[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            T[i][j] = dot3(R[3 * i + 0], R[3 * i + 1], R[3 * i + 2], S[0][j], S[1][j], S[2][j]);
+    out[0] = dot3(T[0][0], T[0][1], T[0][2], R[0], R[1], R[2]);
+    out[1] = dot3(T[0][0], T[0][1], T[0][2], R[3], R[4], R[5]);
+    out[2] = dot3(T[0][0], T[0][1], T[0][2], R[6], R[7], R[8]);
+    out[3] = dot3(T[1][0], T[1][1], T[1][2], R[3], R[4], R[5]);
+    out[4] = dot3(T[1][0], T[1][1], T[1][2], R[6], R[7], R[8]);
+    out[5] = dot3(T[2][0], T[2][1], T[2][2], R[6], R[7], R[8]);
+}
+
+// ---- upload: AoS inputs -> 16-byte planes ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, const float *means, const float *quats,
+                                                  const float *scales, const float *cov6, const float *opac,
+                                                  const float *colors, int coeff_floats, int planes,
+                                                  const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2, float4 *col)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gbits = __uint_as_float(gid ? (unsigned)gid[i] : 0u);
+    g0[i] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+    if (quats) {
+        g1[i] = make_float4(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]);
+        g2[i] = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], gbits);
+    } else {
+        const float *c = cov6 + 6 * i;
+        g1[i] = make_float4(c[0], c[1], c[2], c[3]);
+        g2[i] = make_float4(c[4], c[5], 0.0f, gbits);
+    }
+    const float *src = colors + (int64_t)coeff_floats * i;
+    for (int p = 0; p < planes; ++p) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (4 * p + k < coeff_floats) ? src[4 * p + k] : 0.0f;
+        col[(int64_t)p * n_pad + i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- T2: SH colour from register-resident coefficients -----------------------------------------
+template <int DEG>
+DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
+{
+    float inorm = 1.0f / sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+    float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z;
+    float fC1 = fma_(x, x, -(y * y));
+    float fS1 = 2.0f * x * y;
+    float pSH6 = fma_(0.9461746957575601f, z2, -0.3153915652525201f);
+    float pSH7 = fTmp0B * x;
+    float pSH5 = fTmp0B * y;
+    float pSH8 = 0.5462742152960395f * fC1;
+    float pSH4 = 0.5462742152960395f * fS1;
+    float fTmp0C = fma_(-2.285228997322329f, z2, 0.4570457994644658f);
+    float fTmp1B = 1.445305721320277f * z;
+    float fC2 = fma_(x, fC1, -(y * fS1));
+    float fS2 = fma_(x, fS1, y * fC1);
+    float pSH12 = z * fma_(1.865881662950577f, z2, -1.119528997770346f);
+    float pSH13 = fTmp0C * x;
+    float pSH11 = fTmp0C * y;
+    float pSH14 = fTmp1B * fC1;
+    float pSH10 = fTmp1B * fS1;
+    float pSH15 = -0.5900435899266435f * fC2;
+    float pSH9 = -0.5900435899266435f * fS2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = 0.2820947917738781f * sh[0 * 3 + c];
+        if constexpr (DEG >= 1) {
+            float t = fma_(-x, sh[3 * 3 + c], fma_(z, sh[2 * 3 + c], (-y) * sh[1 * 3 + c]));
+            r = fma_(0.48860251190292f, t, r);
+        }
+        if constexpr (DEG >= 2) {
+            r = fma_(pSH4, sh[4 * 3 + c], r);
+            r = fma_(pSH5, sh[5 * 3 + c], r);
+            r = fma_(pSH6, sh[6 * 3 + c], r);
+            r = fma_(pSH7, sh[7 * 3 + c], r);
+            r = fma_(pSH8, sh[8 * 3 + c], r);
+        }
+        if constexpr (DEG >= 3) {
+            r = fma_(pSH9, sh[9 * 3 + c], r);
+            r = fma_(pSH10, sh[10 * 3 + c], r);
+            r = fma_(pSH11, sh[11 * 3 + c], r);
+            r = fma_(pSH12, sh[12 * 3 + c], r);
+            r = fma_(pSH13, sh[13 * 3 + c], r);
+            r = fma_(pSH14, sh[14 * 3 + c], r);
+            r = fma_(pSH15, sh[15 * 3 + c], r);
+        }
+        rgb[c] = fmaxf(r + 0.5f, 0.0f);
+    }
+}
+
+// Visit every tile of a rectangle.  Small rectangles are walked by their own lane; a lane with a
+// large rectangle hands it to the whole wave (64 lanes stride over its tiles) so that one
+// screen-filling Gaussian does not serialise a wave.  v0/v1 are the owning lane's payload; they
+// are broadcast while the wave is still convergent (a cross-lane read of an inactive lane
+// returns 0), then handed to emit(tile, v0, v1).  Must be reached by all 64 lanes.
+constexpr int kSmallRect = 8;
+
+template <typename F>
+DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, F emit)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = x1 - x0;
+    const int area = active ? w * (y1 - y0) : 0;
+    if (area > 0 && area <= kSmallRect) {
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) emit(ty * tw + tx, v0, v1);
+    }
+    unsigned long long big = __ballot(area > kSmallRect);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
+        const int bw = __shfl(w, src), ba = __shfl(area, src);
+        const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
+        for (int i = lane; i < ba; i += 64) emit((by0 + i / bw) * tw + bx0 + i % bw, b0, b1);
+    }
+}
+
+// ---- k_project: T1 + T2 + tile counts ----------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(256) void k_project(SasScene s, SasCam c, SasFrame f)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = i < s.n;
+    bool vis = false;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (in_range) {
+        const float4 a0 = s.g0[i];
+        const float4 a1 = s.g1[i];
+        const float4 a2 = s.g2[i];
+        float m[3] = {a0.x, a0.y, a0.z};
+        const float op = a0.w;
+        const float *G = nullptr;
+        if (s.group_Rt) {
+            G = s.group_Rt + 12 * (__float_as_uint(a2.w) & 255u);
+            float mg0 = affine3(G[0], G[1], G[2], G[3], m[0], m[1], m[2]);
+            float mg1 = affine3(G[4], G[5], G[6], G[7], m[0], m[1], m[2]);
+            float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
+            m[0] = mg0; m[1] = mg1; m[2] = mg2;
+        }
+        const float x = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);
+        const float y = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
+        const float z = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
+        bool ok = !(z < kNear || z > kFar);
+        ok = ok && !(op < kAlphaThr);   // opacity cull moved up: it has no side effect before the det test
+        if (ok) {
+            float cov[6];
+            if (!s.cov_mode) {
+                float qw = a1.x, qx = a1.y, qy = a1.z, qz = a1.w;
+                float n2 = fma_(qz, qz, fma_(qy, qy, fma_(qx, qx, qw * qw)));
+                float inv = 1.0f / sqrtf(n2);
+                qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+                float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+                float xy = qx * qy, xz = qx * qz, yz = qy * qz;
+                float wx = qw * qx, wy = qw * qy, wz = qw * qz;
+                float R[9];
+                R[0] = fma_(-2.0f, y2 + z2, 1.0f); R[1] = 2.0f * (xy - wz);           R[2] = 2.0f * (xz + wy);
+                R[3] = 2.0f * (xy + wz);           R[4] = fma_(-2.0f, x2 + z2, 1.0f); R[5] = 2.0f * (yz - wx);
+                R[6] = 2.0f * (xz - wy);           R[7] = 2.0f * (yz + wx);           R[8] = fma_(-2.0f, x2 + y2, 1.0f);
+                if (G) {
+                    float R2[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            R2[3 * r + k] = dot3(G[4 * r + 0], G[4 * r + 1], G[4 * r + 2], R[0 + k], R[3 + k], R[6 + k]);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R[k] = R2[k];
+                }
+                const float sc[3] = {a2.x, a2.y, a2.z};
+                float M[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) M[3 * r + k] = R[3 * r + k] * sc[k];
+                cov[0] = dot3(M[0], M[1], M[2], M[0], M[1], M[2]);
+                cov[1] = dot3(M[0], M[1], M[2], M[3], M[4], M[5]);
+                cov[2] = dot3(M[0], M[1], M[2], M[6], M[7], M[8]);
+                cov[3] = dot3(M[3], M[4], M[5], M[3], M[4], M[5]);
+                cov[4] = dot3(M[3], M[4], M[5], M[6], M[7], M[8]);
+                cov[5] = dot3(M[6], M[7], M[8], M[6], M[7], M[8]);
+            } else {
+                cov[0] = a1.x; cov[1] = a1.y; cov[2] = a1.z; cov[3] = a1.w; cov[4] = a2.x; cov[5] = a2.y;
+                if (G) {
+                    const float Rg[9] = {G[0], G[1], G[2], G[4], G[5], G[6], G[8], G[9], G[10]};
+                    float c2[6];
+                    rot_sym3(Rg, cov, c2);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) cov[k] = c2[k];
+                }
+            }
+            float cc3[6];
+            rot_sym3(c.R, cov, cc3);
+
+            const float rz = 1.0f / z;
+            const float rz2 = rz * rz;
+            const float tx = z * fminf(c.lim_x_pos, fmaxf(-c.lim_x_neg, x * rz));
+            const float ty = z * fminf(c.lim_y_pos, fmaxf(-c.lim_y_neg, y * rz));
+            const float ja = c.fx * rz, jb = -((c.fx * tx) * rz2);
+            const float jc = c.fy * rz, jd = -((c.fy * ty) * rz2);
+            const float t00 = fma_(jb, cc3[2], ja * cc3[0]);
+            const float t01 = fma_(jb, cc3[4], ja * cc3[1]);
+            const float t02 = fma_(jb, cc3[5], ja * cc3[2]);
+            const float t11 = fma_(jd, cc3[4], jc * cc3[3]);
+            const float t12 = fma_(jd, cc3[5], jc * cc3[4]);
+            float c00 = fma_(t02, jb, t00 * ja);
+            const float c01 = fma_(t02, jd, t01 * jc);
+            float c11 = fma_(t12, jd, t11 * jc);
+            const float mx = fma_(c.fx, x * rz, c.cx);
+            const float my = fma_(c.fy, y * rz, c.cy);
+            c00 += kEps2d;
+            c11 += kEps2d;
+            const float det = fma_(c00, c11, -(c01 * c01));
+            if (det > 0.0f) {
+                const float inv_det = 1.0f / det;
+                const float ca = c11 * inv_det, cb = -c01 * inv_det, ccn = c00 * inv_det;
+                const float lnq = c_logf(op / kAlphaThr);
+                const float extent = fminf(3.33f, sqrtf(2.0f * lnq));
+                const float b = 0.5f * (c00 + c11);
+                const float tmp = sqrtf(fmaxf(0.01f, fma_(b, b, -det)));
+                const float v1 = b + tmp;
+                const float r1 = extent * sqrtf(v1);
+                const float rx = ceilf(fminf(extent * sqrtf(c00), r1));
+                const float ry = ceilf(fminf(extent * sqrtf(c11), r1));
+                bool keep = !(rx <= 0.0f && ry <= 0.0f);
+                keep = keep && !(mx + rx <= 0.0f || mx - rx >= c.Wf || my + ry <= 0.0f || my - ry >= c.Hf);
+                keep = keep && rx > 0.0f && ry > 0.0f;
+                if (keep) {
+                    vis = true;
+                    // T3 tile rectangle
+                    const float ts = (float)SAS_TILE;
+                    const float trx = rx / ts, try_ = ry / ts;
+                    const float ttx = mx / ts, tty = my / ts;
+                    const float twf = (float)c.tw, thf = (float)c.th;
+                    x0 = (int)fminf(fmaxf(floorf(ttx - trx), 0.0f), twf);
+                    x1 = (int)fminf(fmaxf(ceilf(ttx + trx), 0.0f), twf);
+                    y0 = (int)fminf(fmaxf(floorf(tty - try_), 0.0f), thf);
+                    y1 = (int)fminf(fmaxf(ceilf(tty + try_), 0.0f), thf);
+                    // colour
+                    float rgb[3];
+                    if constexpr (DEG >= 0) {
+                        constexpr int KF = 3 * (DEG + 1) * (DEG + 1);
+                        constexpr int PL = (KF + 3) / 4;
+                        float sh[PL * 4];
+#pragma unroll
+                        for (int p = 0; p < PL; ++p) {
+                            const float4 v = s.col[(int64_t)p * s.n_pad + i];
+                            sh[4 * p] = v.x; sh[4 * p + 1] = v.y; sh[4 * p + 2] = v.z; sh[4 * p + 3] = v.w;
+                        }
+                        sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
+                    } else {
+                        const float4 v = s.col[i];
+                        rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
+                    }
+                    // conservative skip threshold for the blend stage: alpha >= 1/255 implies
+                    // sigma <= ln(255 op) + rounding; 1e-3 is > 100x the worst rounding.
+                    const float thr = lnq + 1e-3f;
+                    f.rec[3 * i + 0] = make_float4(mx, my, ca, cb);
+                    f.rec[3 * i + 1] = make_float4(ccn, op, thr, z);
+                    f.rec[3 * i + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                    f.info[i] = make_uint4((unsigned)x0 | ((unsigned)x1 << 16), (unsigned)y0 | ((unsigned)y1 << 16),
+                                           __float_as_uint(z), (unsigned)(int)rx | ((unsigned)(int)ry << 16));
+                }
+            }
+        }
+        if (!vis) f.info[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // per-tile counts
+    for_each_tile(vis, x0, x1, y0, y1, c.tw, 0u, 0u,
+                  [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
+    const unsigned long long vb = __ballot(vis);
+    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&f.stats[0], (unsigned)__popcll(vb));
+}
+
+// ---- k_scan: exclusive scan over tiles (one workgroup) ------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    int maxlen = 0;
+    for (int base = 0; base < tiles; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < tiles) ? f.tile_count[i] : 0;
+        maxlen = max(maxlen, v);
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        const int excl = carry + woff + incl - v;
+        if (i < tiles) { f.tile_offset[i] = excl; f.tile_cursor[i] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d));
+    if (lane == 0) atomicMax(&f.stats[4], (unsigned)maxlen);
+    if (tid == 0) {
+        const int total = carry_s;
+        f.tile_offset[tiles] = total;
+        f.stats[1] = (unsigned)total;
+        if ((long long)total > f.cap) f.stats[2] = 1u;
+    }
+}
+
+// ---- k_scatter: T3 emit ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame f)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint4 inf = make_uint4(0u, 0u, 0u, 0u);
+    if (i < s.n) inf = f.info[i];
+    const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
+    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
+    const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+    for_each_tile(x1 > x0 && y1 > y0, x0, x1, y0, y1, c.tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
+        const int pos = atomicAdd(&f.tile_cursor[tile], 1);
+        if ((long long)pos < f.cap) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
+    });
+}
+
+// ---- k_sort: per-tile ascending sort of 64-bit keys ---------------------------------------------
+__global__ __launch_bounds__(256) void k_sort(SasFrame f)
+{
+    __shared__ unsigned long long sk[SAS_SORT_LDS_CAP];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const long long beg = f.tile_offset[t];
+    long long end = f.tile_offset[t + 1];
+    if (end > f.cap) end = f.cap;
+    const int n = (int)(end - beg);
+    if (n <= 0) return;
+    unsigned long long *g = f.keys + beg;
+    int *out = f.sorted_ids + beg;
+    if (n == 1) {
+        if (tid == 0) out[0] = (int)(unsigned)g[0];
+        return;
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    if (n <= SAS_SORT_LDS_CAP) {
+        for (int i = tid; i < P; i += 256) sk[i] = (i < n) ? g[i] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += 256) {
+                    const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int r = l | j;
+                    const bool asc = (l & k) == 0;
+                    const unsigned long long a = sk[l], b = sk[r];
+                    if ((a > b) == asc) { sk[l] = b; sk[r] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < n; i += 256) out[i] = (int)(unsigned)sk[i];
+    } else {
+        // Rare: list longer than the LDS capacity.  Same network, all-ascending form (first step
+        // of each merge mirrors), virtual +inf padding, operating on the global segment.
+        for (int k = 2; k <= P; k <<= 1) {
+            const int hk = k >> 1;
+            for (int p = tid; p < (P >> 1); p += 256) {
+                const int blk = (p / hk) * k, o = p % hk;
+                const int l = blk + o, r = blk + k - 1 - o;
+                if (r < n) {
+                    const unsigned long long a = g[l], b = g[r];
+                    if (a > b) { g[l] = b; g[r] = a; }
+                }
+            }
+            __syncthreads();
+            for (int j = k >> 2; j > 0; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += 256) {
+                    const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int r = l | j;
+                    if (r < n) {
+                        const unsigned long long a = g[l], b = g[r];
+                        if (a > b) { g[l] = b; g[r] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < n; i += 256) out[i] = (int)(unsigned)g[i];
+    }
+}
+
+// ---- k_blend: T6 + T0 epilogue -------------------------------------------------------------------
+// One wave per 16x16 tile.  Lane (lx,ly) in 8x8 owns the four pixels (lx+8qx, ly+8qy): the
+// quadratic form shares its per-column / per-row factors across them (24 VALU ops for 4 sigmas)
+// and each 8x8 quadrant gets its own wave-uniform skip.  A single wave executes its LDS
+// operations in order, so the staged queue needs no barrier.
+struct PixState {
+    float T, r, g, b, d;
+    bool done;
+};
+
+template <bool FAST_EXP>
+DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
+{
+    float E;
+    if (FAST_EXP) E = __expf(-sigma);
+    else E = c_expf(-sigma);
+    const float alpha = fminf(kMaxAlpha, op * E);
+    const bool use = cand && !(alpha < kAlphaThr);
+    const float nT = p.T * (1.0f - alpha);
+    const bool stop = use && (nT <= kTStop);
+    const bool upd = use && !stop;
+    const float vis = alpha * p.T;
+    p.r = upd ? fma_(cr, vis, p.r) : p.r;
+    p.g = upd ? fma_(cg, vis, p.g) : p.g;
+    p.b = upd ? fma_(cb, vis, p.b) : p.b;
+    p.d = upd ? fma_(dep, vis, p.d) : p.d;
+    p.T = upd ? nT : p.T;
+    p.done = p.done || stop;
+}
+
+template <bool FAST_EXP>
+__global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o, long long n_gauss)
+{
+    __shared__ float4 q0[64], q1[64], q2[64];
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int tx = tile % c.tw, ty = tile / c.tw;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int ix0 = tx * SAS_TILE + lx, ix1 = ix0 + 8;
+    const int iy0 = ty * SAS_TILE + ly, iy1 = iy0 + 8;
+    const float px0 = (float)ix0 + 0.5f, px1 = (float)ix1 + 0.5f;
+    const float py0 = (float)iy0 + 0.5f, py1 = (float)iy1 + 0.5f;
+    const bool in00 = ix0 < c.W && iy0 < c.H, in10 = ix1 < c.W && iy0 < c.H;
+    const bool in01 = ix0 < c.W && iy1 < c.H, in11 = ix1 < c.W && iy1 < c.H;
+    PixState p00 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in00}, p10 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in10};
+    PixState p01 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in01}, p11 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in11};
+
+    const long long beg = f.tile_offset[tile];
+    long long end = f.tile_offset[tile + 1];
+    if (end > f.cap) end = f.cap;
+
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+    auto fetch = [&](long long at) {
+        const long long idx = at + lane;
+        if (idx < end) {
+            long long id = (unsigned)f.sorted_ids[idx];
+            if (id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
+            ra = f.rec[3 * id + 0];
+            rb = f.rec[3 * id + 1];
+            rc = f.rec[3 * id + 2];
+        }
+    };
+    if (beg < end) fetch(beg);
+    for (long long at = beg; at < end; at += 64) {
+        q0[lane] = ra; q1[lane] = rb; q2[lane] = rc;
+        __builtin_amdgcn_wave_barrier();
+        if (at + 64 < end) fetch(at + 64);   // next batch in flight while this one is blended
+        const int cnt = (int)((end - at) < 64 ? (end - at) : 64);
+        for (int k = 0; k < cnt; ++k) {
+            const float4 A = q0[k], B = q1[k], C = q2[k];
+            const float dx0 = A.x - px0, dx1 = A.x - px1;
+            const float dy0 = A.y - py0, dy1 = A.y - py1;
+            const float ax0 = (A.z * dx0) * dx0, ax1 = (A.z * dx1) * dx1;
+            const float cy0 = B.x * dy0, cy1 = B.x * dy1;
+            const float bx0 = A.w * dx0, bx1 = A.w * dx1;
+            const float s00 = fma_(0.5f, fma_(cy0, dy0, ax0), bx0 * dy0);
+            const float s10 = fma_(0.5f, fma_(cy0, dy0, ax1), bx1 * dy0);
+            const float s01 = fma_(0.5f, fma_(cy1, dy1, ax0), bx0 * dy1);
+            const float s11 = fma_(0.5f, fma_(cy1, dy1, ax1), bx1 * dy1);
+            const float thr = B.z;
+            const bool c00 = !p00.done && s00 >= 0.0f, c10 = !p10.done && s10 >= 0.0f;
+            const bool c01 = !p01.done && s01 >= 0.0f, c11 = !p11.done && s11 >= 0.0f;
+            if (__any(c00 && s00 <= thr)) blend_one<FAST_EXP>(p00, c00, s00, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c10 && s10 <= thr)) blend_one<FAST_EXP>(p10, c10, s10, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c01 && s01 <= thr)) blend_one<FAST_EXP>(p01, c01, s01, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c11 && s11 <= thr)) blend_one<FAST_EXP>(p11, c11, s11, B.y, C.x, C.y, C.z, B.w);
+            if ((k & 15) == 15 && __all(p00.done && p10.done && p01.done && p11.done)) break;
+        }
+        if (__all(p00.done && p10.done && p01.done && p11.done)) break;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    float maxed = 0.0f;
+    auto finish = [&](const PixState &p, bool inside, int ix, int iy) {
+        if (!inside) return;
+        const float a = 1.0f - p.T;
+        const float ED = p.d / fmaxf(a, 1e-10f);
+        maxed = fmaxf(maxed, ED);
+        const long long pix = (long long)iy * c.W + ix;
+        const float w = 1.0f - a;
+        float v0 = p.r + w * o.bg[0], v1 = p.g + w * o.bg[1], v2 = p.b + w * o.bg[2];
+        v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
+        v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
+        v2 = fminf(fmaxf(v2, 0.0f), 1.0f);
+        if (o.rgb) { o.rgb[3 * pix] = v0; o.rgb[3 * pix + 1] = v1; o.rgb[3 * pix + 2] = v2; }
+        if (o.alpha) o.alpha[pix] = a;
+        if (o.depth) o.depth[pix] = ED;
+        if (o.rgb8) {
+            o.rgb8[3 * pix] = (uint8_t)(int)floorf(fma_(v0, 255.0f, 0.5f));
+            o.rgb8[3 * pix + 1] = (uint8_t)(int)floorf(fma_(v1, 255.0f, 0.5f));
+            o.rgb8[3 * pix + 2] = (uint8_t)(int)floorf(fma_(v2, 255.0f, 0.5f));
+        }
+    };
+    finish(p00, in00, ix0, iy0);
+    finish(p10, in10, ix1, iy0);
+    finish(p01, in01, ix0, iy1);
+    finish(p11, in11, ix1, iy1);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
+    if (lane == 0 && maxed > 0.0f) atomicMax(&f.stats[3], __float_as_uint(maxed));
+}
+
+// depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
+__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *stats, float *depth, long long npix)
+{
+    const float mx = __uint_as_float(stats[3]);
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
+        if (depth[p] == 0.0f) depth[p] = mx;
+}
+
+}  // namespace
+
+// ---- launchers -------------------------------------------------------------------------------------
+void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const float *means, const float *quats,
+                         const float *scales, const float *cov6, const float *opac, const float *colors,
+                         int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
+                         float4 *col)
+{
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, n, n_pad, means, quats, scales, cov6, opac, colors,
+                       coeff_floats, planes, gid, g0, g1, g2, col);
+}
+
+void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f)
+{
+    if (s.n <= 0) return;
+    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    switch (s.sh_degree) {
+        case 0: hipLaunchKernelGGL(k_project<0>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+        case 1: hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+        case 2: hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+        case 3: hipLaunchKernelGGL(k_project<3>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+        default: hipLaunchKernelGGL(k_project<-1>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+    }
+}
+
+void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, f, c.tw * c.th);
+}
+
+void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f)
+{
+    if (s.n <= 0) return;
+    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, c, f);
+}
+
+void sas_launch_sort(hipStream_t st, const SasCam &c, const SasFrame &f)
+{
+    hipLaunchKernelGGL(k_sort, dim3(c.tw * c.th), dim3(256), 0, st, f);
+}
+
+void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
+                      bool fast_exp)
+{
+    const unsigned grid = (unsigned)(c.tw * c.th);
+    const long long n = s.n > 0 ? s.n : 1;
+    if (fast_exp) hipLaunchKernelGGL(k_blend<true>, dim3(grid), dim3(64), 0, st, c, f, o, n);
+    else hipLaunchKernelGGL(k_blend<false>, dim3(grid), dim3(64), 0, st, c, f, o, n);
+}
+
+void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth)
+{
+    const long long npix = (long long)c.W * c.H;
+    unsigned grid = (unsigned)((npix + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_depth_fill, dim3(grid), dim3(256), 0, st, (const unsigned *)f.stats, depth, npix);
+}

@@ -1,0 +1,190 @@
+"""Object wrapper over the C ABI: one ``Rasterizer`` = one ``sas_ctx`` on one GPU.
+
+PyTorch is plumbing here (device memory for the outputs, the current HIP stream); all
+arithmetic of the frame happens in libsas_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Iterable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import SasError
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+def _as_f32(a: ArrayLike, shape: Tuple[int, ...], name: str):
+    """Return (keepalive, pointer) of a contiguous float32 array with the given shape."""
+    if isinstance(a, torch.Tensor):
+        t = a.detach()
+        if t.dtype != torch.float32:
+            t = t.float()
+        t = t.reshape(shape).contiguous()
+        return t, ctypes.c_void_p(t.data_ptr())
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(shape)
+    return arr, arr.ctypes.data_as(ctypes.c_void_p)
+
+
+def cov3x3_to_cov6(cov: ArrayLike) -> ArrayLike:
+    """[n,3,3] symmetric -> [n,6] (xx xy xz yy yz zz), the viser `covariances` argument (Door B)."""
+    if isinstance(cov, torch.Tensor):
+        c = cov.reshape(-1, 3, 3)
+        return torch.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], dim=1).contiguous()
+    c = np.asarray(cov, dtype=np.float32).reshape(-1, 3, 3)
+    return np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+
+
+class Rasterizer:
+    """MI355X Gaussian-splat rasterizer context (HIP, gfx950)."""
+
+    def __init__(self, device: Union[int, str, torch.device] = 0):
+        if not torch.cuda.is_available():
+            raise SasError("no HIP device visible: the render path has no CPU fallback")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise SasError(f"Rasterizer needs a cuda (HIP) device, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self._L = _capi.lib()
+        self._ctx = ctypes.c_void_p()
+        rc = self._L.sas_create(self.device.index, ctypes.byref(self._ctx))
+        if rc != 0:
+            raise SasError(f"sas_create(device={self.device.index}) failed with status {rc}")
+        self.n = 0
+        self.n_groups = 0
+        self._keep = None  # outputs of an in-flight async frame
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.sas_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        _capi.check(self._ctx, rc, what)
+
+    # -- scene ------------------------------------------------------------------------------
+    def upload(self, means: ArrayLike, opacities: ArrayLike, colors: ArrayLike, *, quats: Optional[ArrayLike] = None,
+               scales: Optional[ArrayLike] = None, covariances: Optional[ArrayLike] = None, sh_degree: int = 3,
+               group_id: Optional[ArrayLike] = None, n_groups: int = 0) -> None:
+        """Replace the scene.  ``sh_degree < 0``: ``colors`` is final RGB [n,3] (Door B)."""
+        n = int(means.shape[0])
+        keep = []
+        m, pm = _as_f32(means, (n, 3), "means"); keep.append(m)
+        o, po = _as_f32(opacities, (n,), "opacities"); keep.append(o)
+        kk = (sh_degree + 1) ** 2 if sh_degree >= 0 else 1
+        c, pc = _as_f32(colors, (n, kk, 3), "colors"); keep.append(c)
+        pq = ps = pcov = None
+        if quats is not None and scales is not None:
+            q, pq = _as_f32(quats, (n, 4), "quats"); keep.append(q)
+            s, ps = _as_f32(scales, (n, 3), "scales"); keep.append(s)
+        elif covariances is not None:
+            cov = covariances
+            if tuple(cov.shape[1:]) == (3, 3):
+                cov = cov3x3_to_cov6(cov)
+            cv, pcov = _as_f32(cov, (n, 6), "covariances"); keep.append(cv)
+        else:
+            raise ValueError("need quats+scales or covariances")
+        pg = None
+        if group_id is not None:
+            if isinstance(group_id, torch.Tensor):
+                g = group_id.detach().to(torch.uint8).contiguous()
+                pg = ctypes.c_void_p(g.data_ptr())
+            else:
+                g = np.ascontiguousarray(np.asarray(group_id, dtype=np.uint8))
+                pg = g.ctypes.data_as(ctypes.c_void_p)
+            keep.append(g)
+            if n_groups <= 0:
+                n_groups = int(g.max()) + 1 if n > 0 else 1
+        torch.cuda.synchronize(self.device)  # device-resident inputs must be complete before the copy
+        self._check(self._L.sas_scene_upload(self._ctx, n, pm, pq, ps, pcov, po, pc, int(sh_degree), pg, int(n_groups)),
+                    "sas_scene_upload")
+        self.n = n
+        self.n_groups = int(n_groups) if group_id is not None else 0
+
+    def set_group_poses(self, Rt: ArrayLike) -> None:
+        """[G,12] (or [G,3,4]) row-major (R|t) per splat group."""
+        arr = np.ascontiguousarray(np.asarray(Rt.cpu() if isinstance(Rt, torch.Tensor) else Rt, dtype=np.float32)).reshape(-1, 12)
+        self._check(self._L.sas_set_group_poses(self._ctx, arr.shape[0], arr.ctypes.data_as(ctypes.c_void_p)),
+                    "sas_set_group_poses")
+
+    # -- frames -----------------------------------------------------------------------------
+    def render(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
+               background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb", "alpha", "depth"),
+               depth_fill_max: bool = False, fast_exp: bool = False, timing: bool = False, block: bool = True,
+               out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Render one view; returns device tensors ``rgb [H,W,3]``, ``alpha [H,W,1]``,
+        ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``."""
+        V = np.ascontiguousarray(np.asarray(viewmat.cpu() if isinstance(viewmat, torch.Tensor) else viewmat, dtype=np.float32)).reshape(16)
+        Kc = np.ascontiguousarray(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float32)).reshape(9)
+        bg = np.ascontiguousarray(np.asarray(background, dtype=np.float32)).reshape(3)
+        W, H = int(width), int(height)
+        want = tuple(want)
+        res: Dict[str, torch.Tensor] = {}
+        shapes = {"rgb": ((H, W, 3), torch.float32), "alpha": ((H, W, 1), torch.float32),
+                  "depth": ((H, W, 1), torch.float32), "rgb8": ((H, W, 3), torch.uint8)}
+        for k in want:
+            if k not in shapes:
+                raise ValueError(f"unknown output {k!r}")
+            shp, dt = shapes[k]
+            if out is not None and k in out:
+                t = out[k]
+                if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError(f"out[{k!r}] must be a contiguous {dt} tensor {shp} on {self.device}")
+            else:
+                t = torch.empty(shp, dtype=dt, device=self.device)
+            res[k] = t
+        ptr = lambda k: ctypes.c_void_p(res[k].data_ptr()) if k in res else None
+        flags = (_capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0) | (_capi.SAS_FAST_EXP if fast_exp else 0) | \
+                (_capi.SAS_TIMING if timing else 0) | (0 if block else _capi.SAS_ASYNC)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._L.sas_render(self._ctx, V.ctypes.data_as(ctypes.c_void_p), Kc.ctypes.data_as(ctypes.c_void_p), W, H,
+                                bg.ctypes.data_as(ctypes.c_void_p), flags, ptr("rgb"), ptr("alpha"), ptr("depth"),
+                                ptr("rgb8"), stream)
+        self._check(rc, "sas_render")
+        self._keep = None if block else res
+        return res
+
+    def wait(self) -> None:
+        self._check(self._L.sas_wait(self._ctx), "sas_wait")
+        self._keep = None
+
+    # -- introspection ------------------------------------------------------------------------
+    def stage_times(self) -> Dict[str, float]:
+        ms = (ctypes.c_float * len(_capi.STAGE_NAMES))()
+        self._check(self._L.sas_stage_times(self._ctx, ms, len(_capi.STAGE_NAMES)), "sas_stage_times")
+        return dict(zip(_capi.STAGE_NAMES, [float(x) for x in ms]))
+
+    def stats(self) -> Dict[str, int]:
+        st = (ctypes.c_int64 * len(_capi.STAT_NAMES))()
+        self._check(self._L.sas_frame_stats(self._ctx, st, len(_capi.STAT_NAMES)), "sas_frame_stats")
+        return dict(zip(_capi.STAT_NAMES, [int(x) for x in st]))
+
+    def read_projection(self) -> Dict[str, np.ndarray]:
+        n = self.n
+        radii = np.zeros((n, 2), np.int32)
+        means2d = np.zeros((n, 2), np.float32)
+        depths = np.zeros((n,), np.float32)
+        conics = np.zeros((n, 3), np.float32)
+        colors = np.zeros((n, 3), np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._L.sas_read_projection(self._ctx, p(radii), p(means2d), p(depths), p(conics), p(colors)),
+                    "sas_read_projection")
+        return dict(radii=radii, means2d=means2d, depths=depths, conics=conics, colors=colors)
+
+    def read_tile_lists(self, tiles: int) -> Dict[str, np.ndarray]:
+        m = self.stats()["n_isect"]
+        off = np.zeros((tiles + 1,), np.int32)
+        ids = np.zeros((max(m, 1),), np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._L.sas_read_tile_lists(self._ctx, p(off), p(ids), m), "sas_read_tile_lists")
+        return dict(tile_offsets=off, sorted_ids=ids[:m])

