@@ -50,7 +50,8 @@ typedef enum {
 enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT, SAS_T_BLEND, SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame */
-enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS, SAS_S_COUNT };
+enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
+       SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);

@@ -18,7 +18,7 @@ SAS_FAST_EXP = 4
 SAS_TIMING = 8
 
 STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "total")
-STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows")
+STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses")
 
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (

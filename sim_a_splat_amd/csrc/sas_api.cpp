@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -38,7 +39,8 @@ struct sas_ctx {
     int device = 0;
     std::string err;
     // scene
-    DevBuf g0, g1, g2, col, groups;
+    DevBuf g0, g1, g2, col, groups, perm, inv_perm;
+    std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
     std::vector<float> group_host;
@@ -51,7 +53,7 @@ struct sas_ctx {
     RenderArgs last;
     SasCam cam{};
     bool pending = false;
-    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0};
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
     bool ev_made = false, ev_valid = false;
@@ -98,6 +100,59 @@ void release(DevBuf &b)
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
+}
+
+// 3-D Hilbert index (Skilling's transpose form), `bits` per axis.  Storage order of the scene:
+// consecutive Gaussians are spatial neighbours, so a workgroup's tile window is compact.
+uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits)
+{
+    uint32_t X[3] = {x, y, z};
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    for (int i = 0; i < 3; ++i) X[i] ^= t;
+    uint32_t code = 0;
+    for (int b = bits - 1; b >= 0; --b)
+        for (int i = 0; i < 3; ++i) code = (code << 1) | ((X[i] >> b) & 1u);
+    return code;
+}
+
+// perm[slot] = caller index, ordered by (group, Hilbert index of the mean, caller index).
+void storage_order(int64_t n, const float *means, const uint8_t *gid, std::vector<int> &perm)
+{
+    perm.resize((size_t)n);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = means[3 * i + k];
+            if (std::isfinite(v)) { lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
+        }
+    float inv[3];
+    for (int k = 0; k < 3; ++k) inv[k] = (hi[k] > lo[k]) ? 1023.0f / (hi[k] - lo[k]) : 0.0f;
+    std::vector<uint64_t> key((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float v = means[3 * i + k];
+            float u = std::isfinite(v) ? (v - lo[k]) * inv[k] : 0.0f;
+            u = std::min(std::max(u, 0.0f), 1023.0f);
+            q[k] = (uint32_t)u;
+        }
+        const uint64_t g = gid ? gid[i] : 0;
+        key[(size_t)i] = (g << 32) | hilbert3(q[0], q[1], q[2], 10);
+    }
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int)i;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
 }
 
 // Camera constants in the oracle's operation order (oracle/sas_oracle.c cam_from, project_one).
@@ -181,7 +236,7 @@ int enqueue_frame(sas_ctx *c)
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     sas_launch_scatter(st, c->scene, cam, f);
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    sas_launch_sort(st, cam, f);
+    sas_launch_sort(st, c->scene, cam, f, c->stats[SAS_S_MAX_TILE_LEN]);
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0);
     if (a.depth && (a.flags & SAS_DEPTH_FILL_MAX)) sas_launch_depth_fill(st, cam, f, a.depth);
@@ -204,6 +259,7 @@ int finish_frame(sas_ctx *c)
         c->stats[SAS_S_MAX_TILE_LEN] = s[4];
         c->stats[SAS_S_CAPACITY] = c->cap;
         c->stats[SAS_S_REGROWS] = c->regrows;
+        c->stats[SAS_S_WINDOW_MISSES] = s[5];
         if (c->ev_valid) {
             for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], c->ev[k], c->ev[k + 1]);
             (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], c->ev[0], c->ev[5]);
@@ -249,7 +305,7 @@ int sas_destroy(sas_ctx *c)
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
     if (c->pending) (void)hipStreamSynchronize(c->last.stream);
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
                       &c->counters})
         release(*b);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
@@ -289,7 +345,26 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     if ((rc = ensure(c, c->g2, sizeof(float4) * np))) return rc;
     if ((rc = ensure(c, c->col, sizeof(float4) * np * planes))) return rc;
 
+    c->perm_host.clear();
+    if ((rc = ensure(c, c->perm, sizeof(int) * np))) return rc;
+    if ((rc = ensure(c, c->inv_perm, sizeof(int) * np))) return rc;
     if (n > 0) {
+        // storage order from host copies of the means / group ids
+        std::vector<float> h_means((size_t)3 * n);
+        std::vector<uint8_t> h_gid;
+        HIP_TRY(c, hipMemcpy(h_means.data(), means, sizeof(float) * 3 * n, hipMemcpyDefault));
+        if (group_id) {
+            h_gid.resize((size_t)n);
+            HIP_TRY(c, hipMemcpy(h_gid.data(), group_id, (size_t)n, hipMemcpyDefault));
+            for (int64_t i = 0; i < n; ++i)
+                if (h_gid[(size_t)i] >= n_groups) return fail(c, SAS_ERR_INVALID, "group_id[%lld]=%d >= n_groups=%d", (long long)i, (int)h_gid[(size_t)i], n_groups);
+        }
+        storage_order(n, h_means.data(), group_id ? h_gid.data() : nullptr, c->perm_host);
+        std::vector<int> inv((size_t)n);
+        for (int64_t j = 0; j < n; ++j) inv[(size_t)c->perm_host[(size_t)j]] = (int)j;
+        HIP_TRY(c, hipMemcpy(c->perm.p, c->perm_host.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->inv_perm.p, inv.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+
         // stage the caller's arrays (host or device) and re-lay them out on the device
         DevBuf s_means, s_q, s_s, s_cov, s_op, s_col, s_gid;
         auto stage = [&](DevBuf &b, const void *src, size_t bytes) -> int {
@@ -306,10 +381,11 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
         if (!rc) rc = stage(s_col, colors, sizeof(float) * (size_t)coeff_floats * n);
         if (!rc && group_id) rc = stage(s_gid, group_id, (size_t)n);
         if (!rc) {
-            sas_launch_relayout(nullptr, n, n_pad, (const float *)s_means.p, (const float *)s_q.p, (const float *)s_s.p,
-                                (const float *)s_cov.p, (const float *)s_op.p, (const float *)s_col.p, coeff_floats,
-                                planes, (const uint8_t *)s_gid.p, (float4 *)c->g0.p, (float4 *)c->g1.p,
-                                (float4 *)c->g2.p, (float4 *)c->col.p);
+            sas_launch_relayout(nullptr, n, n_pad, (const int *)c->perm.p, (const float *)s_means.p,
+                                (const float *)s_q.p, (const float *)s_s.p, (const float *)s_cov.p,
+                                (const float *)s_op.p, (const float *)s_col.p, coeff_floats, planes,
+                                (const uint8_t *)s_gid.p, (float4 *)c->g0.p, (float4 *)c->g1.p, (float4 *)c->g2.p,
+                                (float4 *)c->col.p);
             hipError_t e = hipDeviceSynchronize();
             if (e != hipSuccess) rc = fail(c, SAS_ERR_HIP, "relayout: %s", hipGetErrorString(e));
         }
@@ -322,6 +398,8 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     c->scene.g1 = (const float4 *)c->g1.p;
     c->scene.g2 = (const float4 *)c->g2.p;
     c->scene.col = (const float4 *)c->col.p;
+    c->scene.perm = (const int *)c->perm.p;
+    c->scene.inv_perm = (const int *)c->inv_perm.p;
     c->scene.n = n;
     c->scene.n_pad = n_pad;
     c->scene.sh_degree = deg;
@@ -424,10 +502,11 @@ int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depth
         HIP_TRY(c, hipMemcpy(rec.data(), c->rec.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(info.data(), c->info.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost));
     }
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t rr = info[4 * i + 3];
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t i = c->perm_host[(size_t)j];   // slot j holds the caller's Gaussian i
+        const uint32_t rr = info[4 * j + 3];
         const bool vis = rr != 0;
-        const float *r = &rec[12 * i];
+        const float *r = &rec[12 * j];
         if (radii) { radii[2 * i] = vis ? (int32_t)(rr & 0xffff) : 0; radii[2 * i + 1] = vis ? (int32_t)(rr >> 16) : 0; }
         if (means2d) { means2d[2 * i] = vis ? r[0] : 0.f; means2d[2 * i + 1] = vis ? r[1] : 0.f; }
         if (depths) depths[i] = vis ? r[7] : 0.f;
@@ -454,6 +533,10 @@ int sas_read_tile_lists(sas_ctx *c, int32_t *tile_offsets, int32_t *sorted_ids, 
         if (m > cap) m = cap;
         if (m > c->cap) m = c->cap;
         if (m > 0) HIP_TRY(c, hipMemcpy(sorted_ids, c->ids.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < m; ++k) {   // storage slots -> caller indices
+            const int j = sorted_ids[k];
+            sorted_ids[k] = (j >= 0 && j < c->scene.n) ? c->perm_host[(size_t)j] : -1;
+        }
     }
     return SAS_OK;
 }

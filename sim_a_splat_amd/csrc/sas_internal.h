@@ -4,7 +4,6 @@
 #include <stdint.h>
 
 #define SAS_TILE 16
-#define SAS_SORT_LDS_CAP 4096  // keys sorted inside LDS by one workgroup (32 KiB)
 
 // Per-frame camera constants, computed on the host with the same f32 operations the oracle uses.
 struct SasCam {
@@ -16,7 +15,9 @@ struct SasCam {
     int W, H, tw, th;
 };
 
-// Scene in HBM, re-laid out at upload into 16-byte planes so that lane i of a wave reads
+// Scene in HBM.  At upload the Gaussians are re-ordered along a 3-D Hilbert curve (per splat
+// group) so that the 256 Gaussians of one workgroup project to a compact screen window, and
+// re-laid out into 16-byte planes so that lane i of a wave reads
 // bytes [16 i, 16 i + 16) of every plane: each wave-instruction is one contiguous 1 KiB.
 //   g0[n] = (mean.x, mean.y, mean.z, opacity)
 //   g1[n] = quat wxyz                     | cov xx xy xz yy
@@ -25,6 +26,8 @@ struct SasCam {
 struct SasScene {
     const float4 *g0, *g1, *g2, *col;
     const float *group_Rt;  // [n_groups,12] or nullptr
+    const int *perm;        // [n] slot j holds the caller's Gaussian perm[j] (Hilbert order, by group)
+    const int *inv_perm;    // [n] caller index -> slot
     int64_t n;
     int64_t n_pad;     // plane stride
     int sh_degree;     // -1: col plane 0 holds final rgb
@@ -37,6 +40,7 @@ struct SasScene {
 //        (mean2d.x, mean2d.y, conic.a, conic.b) (conic.c, opacity, skip_threshold, depth) (r, g, b, -)
 //   info[n]        (x0 | x1<<16, y0 | y1<<16, depth bits, rx | ry<<16): tile rectangle, 0 if culled
 //   stats          [0] n_visible [1] n_isect [2] overflow [3] max ED bits [4] max tile length
+//                  [5] workgroups whose screen window did not fit the LDS histogram (direct atomics)
 struct SasFrame {
     float4 *rec;
     uint4 *info;
@@ -56,14 +60,14 @@ struct SasOutputs {
 };
 
 // launchers (sas_kernels.hip)
-void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const float *means, const float *quats,
+void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
                          float4 *col);
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
 void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
-void sas_launch_sort(hipStream_t st, const SasCam &c, const SasFrame &f);
+void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint);
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
                       bool fast_exp);
 void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth);

@@ -89,29 +89,30 @@ DEV void rot_sym3(const float *R, const float *s, float *out)
 }
 
 // ---- upload: AoS inputs -> 16-byte planes ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, const float *means, const float *quats,
-                                                  const float *scales, const float *cov6, const float *opac,
-                                                  const float *colors, int coeff_floats, int planes,
+__global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, const int *perm, const float *means,
+                                                  const float *quats, const float *scales, const float *cov6,
+                                                  const float *opac, const float *colors, int coeff_floats, int planes,
                                                   const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2, float4 *col)
 {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;   // slot
+    if (j >= n) return;
+    const int64_t i = perm[j];                                    // caller's index
     float gbits = __uint_as_float(gid ? (unsigned)gid[i] : 0u);
-    g0[i] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+    g0[j] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
     if (quats) {
-        g1[i] = make_float4(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]);
-        g2[i] = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], gbits);
+        g1[j] = make_float4(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]);
+        g2[j] = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], gbits);
     } else {
         const float *c = cov6 + 6 * i;
-        g1[i] = make_float4(c[0], c[1], c[2], c[3]);
-        g2[i] = make_float4(c[4], c[5], 0.0f, gbits);
+        g1[j] = make_float4(c[0], c[1], c[2], c[3]);
+        g2[j] = make_float4(c[4], c[5], 0.0f, gbits);
     }
     const float *src = colors + (int64_t)coeff_floats * i;
     for (int p = 0; p < planes; ++p) {
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (4 * p + k < coeff_floats) ? src[4 * p + k] : 0.0f;
-        col[(int64_t)p * n_pad + i] = make_float4(v[0], v[1], v[2], v[3]);
+        col[(int64_t)p * n_pad + j] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -194,6 +195,46 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
         const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
         for (int i = lane; i < ba; i += 64) emit((by0 + i / bw) * tw + bx0 + i % bw, b0, b1);
     }
+}
+
+// Workgroup screen window.  The scene is stored along a Hilbert curve, so the 256 Gaussians of a
+// workgroup land in a compact block of tiles: their per-tile counts are accumulated in an LDS
+// histogram over that window and leave the CU as ONE global atomic per touched tile instead of
+// one per intersection (device-scope atomics execute at the memory side: ~10 G/s scattered).
+// Gaussians with a large rectangle stay out of the window and use the wave-cooperative walk.
+constexpr int kHistBins = 2048;  // 8 KiB of LDS
+constexpr int kWinRect = 64;     // largest rectangle (tiles) that takes part in the window
+
+struct Window {
+    int X0, Y0, ww, area;   // origin, width, bin count (0: no participant)
+    bool fits;
+};
+
+DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
+{
+    int mnx = part ? x0 : 0x7fffffff, mny = part ? y0 : 0x7fffffff;
+    int mxx = part ? x1 : 0, mxy = part ? y1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, d));
+        mny = min(mny, __shfl_xor(mny, d));
+        mxx = max(mxx, __shfl_xor(mxx, d));
+        mxy = max(mxy, __shfl_xor(mxy, d));
+    }
+    if (threadIdx.x == 0) { s_win[0] = 0x7fffffff; s_win[1] = 0x7fffffff; s_win[2] = 0; s_win[3] = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_win[0], mnx); atomicMin(&s_win[1], mny);
+        atomicMax(&s_win[2], mxx); atomicMax(&s_win[3], mxy);
+    }
+    __syncthreads();
+    Window w;
+    w.X0 = s_win[0]; w.Y0 = s_win[1];
+    const int X1 = s_win[2], Y1 = s_win[3];
+    w.ww = X1 - w.X0;
+    w.area = (X1 > w.X0 && Y1 > w.Y0) ? w.ww * (Y1 - w.Y0) : 0;
+    w.fits = w.area > 0 && w.area <= kHistBins;
+    return w;
 }
 
 // ---- k_project: T1 + T2 + tile counts ----------------------------------------------------------
@@ -345,8 +386,27 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, SasCam c, SasFrame 
         }
         if (!vis) f.info[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    // per-tile counts
-    for_each_tile(vis, x0, x1, y0, y1, c.tw, 0u, 0u,
+    // per-tile counts: LDS histogram over the workgroup's window, one global atomic per touched tile
+    __shared__ int s_win[4];
+    __shared__ int s_hist[kHistBins];
+    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
+    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
+    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    if (w.fits) {
+        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
+        __syncthreads();
+        if (in_win)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
+        __syncthreads();
+        for (int b = threadIdx.x; b < w.area; b += 256) {
+            const int cnt = s_hist[b];
+            if (cnt) atomicAdd(&f.tile_count[(w.Y0 + b / w.ww) * c.tw + w.X0 + b % w.ww], cnt);
+        }
+    } else if (threadIdx.x == 0 && w.area > 0) {
+        atomicAdd(&f.stats[5], 1u);
+    }
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, c.tw, 0u, 0u,
                   [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
     const unsigned long long vb = __ballot(vis);
     if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&f.stats[0], (unsigned)__popcll(vb));
@@ -394,82 +454,130 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
 }
 
 // ---- k_scatter: T3 emit ---------------------------------------------------------------------------
+// Same window as k_project: count in LDS, reserve one contiguous run per touched tile with a
+// single returning global atomic, then rank inside the run with LDS atomics.  The key carries the
+// CALLER's Gaussian index (perm[slot]) so that depth ties order exactly as in the reference.
 __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame f)
 {
+    __shared__ int s_win[4];
+    __shared__ int s_hist[kHistBins];
+    __shared__ int s_base[kHistBins];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint4 inf = make_uint4(0u, 0u, 0u, 0u);
-    if (i < s.n) inf = f.info[i];
+    unsigned orig = 0;
+    if (i < s.n) { inf = f.info[i]; orig = (unsigned)s.perm[i]; }
     const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
-    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
+    const bool vis = x1 > x0 && y1 > y0;
+    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)orig;
+    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
+    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
+    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    if (w.fits) {
+        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
+        __syncthreads();
+        if (in_win)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
+        __syncthreads();
+        for (int b = threadIdx.x; b < w.area; b += 256) {
+            const int cnt = s_hist[b];
+            s_base[b] = cnt ? atomicAdd(&f.tile_cursor[(w.Y0 + b / w.ww) * c.tw + w.X0 + b % w.ww], cnt) : 0;
+            s_hist[b] = 0;
+        }
+        __syncthreads();
+        if (in_win)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
+                    if (pos < f.cap) f.keys[pos] = key;
+                }
+    }
     const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-    for_each_tile(x1 > x0 && y1 > y0, x0, x1, y0, y1, c.tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, c.tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
         const int pos = atomicAdd(&f.tile_cursor[tile], 1);
         if ((long long)pos < f.cap) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
     });
 }
 
 // ---- k_sort: per-tile ascending sort of 64-bit keys ---------------------------------------------
-__global__ __launch_bounds__(256) void k_sort(SasFrame f)
+// Three size classes are launched over all tiles; a workgroup whose tile is not in its class
+// exits at once.  LDS classes use a bitonic network on (depth bits, caller index) keys, which are
+// unique, so any correct sort reproduces the stable radix order of the reference.  The sorted
+// caller indices are translated to storage slots (inv_perm) on the way out.
+template <int CAP>
+__global__ __launch_bounds__(256) void k_sort_lds(SasFrame f, const int *inv_perm, int lo_excl)
 {
-    __shared__ unsigned long long sk[SAS_SORT_LDS_CAP];
+    __shared__ unsigned long long sk[CAP];
     const int t = blockIdx.x, tid = threadIdx.x;
     const long long beg = f.tile_offset[t];
     long long end = f.tile_offset[t + 1];
     if (end > f.cap) end = f.cap;
     const int n = (int)(end - beg);
-    if (n <= 0) return;
-    unsigned long long *g = f.keys + beg;
+    if (n <= lo_excl || n > CAP) return;
+    const unsigned long long *g = f.keys + beg;
     int *out = f.sorted_ids + beg;
     if (n == 1) {
-        if (tid == 0) out[0] = (int)(unsigned)g[0];
+        if (tid == 0) out[0] = inv_perm[(unsigned)g[0]];
         return;
     }
     int P = 2;
     while (P < n) P <<= 1;
-    if (n <= SAS_SORT_LDS_CAP) {
-        for (int i = tid; i < P; i += 256) sk[i] = (i < n) ? g[i] : ~0ull;
-        __syncthreads();
-        for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int p = tid; p < (P >> 1); p += 256) {
-                    const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                    const int r = l | j;
-                    const bool asc = (l & k) == 0;
-                    const unsigned long long a = sk[l], b = sk[r];
-                    if ((a > b) == asc) { sk[l] = b; sk[r] = a; }
-                }
-                __syncthreads();
+    for (int i = tid; i < P; i += 256) sk[i] = (i < n) ? g[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (P >> 1); p += 256) {
+                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int r = l | j;
+                const bool asc = (l & k) == 0;
+                const unsigned long long a = sk[l], b = sk[r];
+                if ((a > b) == asc) { sk[l] = b; sk[r] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 256) out[i] = inv_perm[(unsigned)sk[i]];
+}
+
+// Lists longer than the largest LDS class: same network in its all-ascending form (the first
+// step of each merge mirrors), virtual +inf padding, in place on the global segment.
+__global__ __launch_bounds__(256) void k_sort_global(SasFrame f, const int *inv_perm, int lo_excl)
+{
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const long long beg = f.tile_offset[t];
+    long long end = f.tile_offset[t + 1];
+    if (end > f.cap) end = f.cap;
+    const int n = (int)(end - beg);
+    if (n <= lo_excl) return;
+    unsigned long long *g = f.keys + beg;
+    int *out = f.sorted_ids + beg;
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = tid; p < (P >> 1); p += 256) {
+            const int blk = (p / hk) * k, o = p % hk;
+            const int l = blk + o, r = blk + k - 1 - o;
+            if (r < n) {
+                const unsigned long long a = g[l], b = g[r];
+                if (a > b) { g[l] = b; g[r] = a; }
             }
         }
-        for (int i = tid; i < n; i += 256) out[i] = (int)(unsigned)sk[i];
-    } else {
-        // Rare: list longer than the LDS capacity.  Same network, all-ascending form (first step
-        // of each merge mirrors), virtual +inf padding, operating on the global segment.
-        for (int k = 2; k <= P; k <<= 1) {
-            const int hk = k >> 1;
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
             for (int p = tid; p < (P >> 1); p += 256) {
-                const int blk = (p / hk) * k, o = p % hk;
-                const int l = blk + o, r = blk + k - 1 - o;
+                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int r = l | j;
                 if (r < n) {
                     const unsigned long long a = g[l], b = g[r];
                     if (a > b) { g[l] = b; g[r] = a; }
                 }
             }
             __syncthreads();
-            for (int j = k >> 2; j > 0; j >>= 1) {
-                for (int p = tid; p < (P >> 1); p += 256) {
-                    const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                    const int r = l | j;
-                    if (r < n) {
-                        const unsigned long long a = g[l], b = g[r];
-                        if (a > b) { g[l] = b; g[r] = a; }
-                    }
-                }
-                __syncthreads();
-            }
         }
-        for (int i = tid; i < n; i += 256) out[i] = (int)(unsigned)g[i];
     }
+    for (int i = tid; i < n; i += 256) out[i] = inv_perm[(unsigned)g[i]];
 }
 
 // ---- k_blend: T6 + T0 epilogue -------------------------------------------------------------------
@@ -482,24 +590,46 @@ struct PixState {
     bool done;
 };
 
+// exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
+// the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
+DEV float c_expf_neg_small(float x)
+{
+    const float t = x * 1.4426950408889634f;
+    const float n = __builtin_rintf(t);
+    const float fr = t - n;
+    float p = 0.0013400432653725147f;
+    p = fma_(p, fr, 0.009676037356257439f);
+    p = fma_(p, fr, 0.05550327152013779f);
+    p = fma_(p, fr, 0.2402210682630539f);
+    p = fma_(p, fr, 0.6931471824645996f);
+    p = fma_(p, fr, 1.0000001192092896f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+// `cand` = pixel alive, sigma >= 0 and sigma <= thr.  sigma > thr implies alpha < 1/255 with a
+// margin far above rounding, so excluding those lanes takes the same decision as the contract.
 template <bool FAST_EXP>
 DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
 {
-    float E;
-    if (FAST_EXP) E = __expf(-sigma);
-    else E = c_expf(-sigma);
-    const float alpha = fminf(kMaxAlpha, op * E);
-    const bool use = cand && !(alpha < kAlphaThr);
-    const float nT = p.T * (1.0f - alpha);
-    const bool stop = use && (nT <= kTStop);
-    const bool upd = use && !stop;
-    const float vis = alpha * p.T;
-    p.r = upd ? fma_(cr, vis, p.r) : p.r;
-    p.g = upd ? fma_(cg, vis, p.g) : p.g;
-    p.b = upd ? fma_(cb, vis, p.b) : p.b;
-    p.d = upd ? fma_(dep, vis, p.d) : p.d;
-    p.T = upd ? nT : p.T;
-    p.done = p.done || stop;
+    if (cand) {
+        float E;
+        if (FAST_EXP) E = __expf(-sigma);
+        else E = c_expf_neg_small(-sigma);
+        const float alpha = fminf(kMaxAlpha, op * E);
+        if (!(alpha < kAlphaThr)) {
+            const float nT = p.T * (1.0f - alpha);
+            if (nT <= kTStop) {
+                p.done = true;
+            } else {
+                const float vis = alpha * p.T;
+                p.r = fma_(cr, vis, p.r);
+                p.g = fma_(cg, vis, p.g);
+                p.b = fma_(cb, vis, p.b);
+                p.d = fma_(dep, vis, p.d);
+                p.T = nT;
+            }
+        }
+    }
 }
 
 template <bool FAST_EXP>
@@ -552,12 +682,12 @@ __global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o
             const float s01 = fma_(0.5f, fma_(cy1, dy1, ax0), bx0 * dy1);
             const float s11 = fma_(0.5f, fma_(cy1, dy1, ax1), bx1 * dy1);
             const float thr = B.z;
-            const bool c00 = !p00.done && s00 >= 0.0f, c10 = !p10.done && s10 >= 0.0f;
-            const bool c01 = !p01.done && s01 >= 0.0f, c11 = !p11.done && s11 >= 0.0f;
-            if (__any(c00 && s00 <= thr)) blend_one<FAST_EXP>(p00, c00, s00, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c10 && s10 <= thr)) blend_one<FAST_EXP>(p10, c10, s10, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c01 && s01 <= thr)) blend_one<FAST_EXP>(p01, c01, s01, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c11 && s11 <= thr)) blend_one<FAST_EXP>(p11, c11, s11, B.y, C.x, C.y, C.z, B.w);
+            const bool c00 = !p00.done && s00 >= 0.0f && s00 <= thr, c10 = !p10.done && s10 >= 0.0f && s10 <= thr;
+            const bool c01 = !p01.done && s01 >= 0.0f && s01 <= thr, c11 = !p11.done && s11 >= 0.0f && s11 <= thr;
+            if (__any(c00)) blend_one<FAST_EXP>(p00, c00, s00, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c10)) blend_one<FAST_EXP>(p10, c10, s10, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c01)) blend_one<FAST_EXP>(p01, c01, s01, B.y, C.x, C.y, C.z, B.w);
+            if (__any(c11)) blend_one<FAST_EXP>(p11, c11, s11, B.y, C.x, C.y, C.z, B.w);
             if ((k & 15) == 15 && __all(p00.done && p10.done && p01.done && p11.done)) break;
         }
         if (__all(p00.done && p10.done && p01.done && p11.done)) break;
@@ -605,14 +735,14 @@ __global__ __launch_bounds__(256) void k_depth_fill(const unsigned *stats, float
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------
-void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const float *means, const float *quats,
+void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
                          float4 *col)
 {
     if (n <= 0) return;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, n, n_pad, means, quats, scales, cov6, opac, colors,
+    hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, n, n_pad, perm, means, quats, scales, cov6, opac, colors,
                        coeff_floats, planes, gid, g0, g1, g2, col);
 }
 
@@ -641,9 +771,15 @@ void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, cons
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, c, f);
 }
 
-void sas_launch_sort(hipStream_t st, const SasCam &c, const SasFrame &f)
+constexpr int kSortSmall = 1024, kSortLarge = 8192;
+
+void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint)
 {
-    hipLaunchKernelGGL(k_sort, dim3(c.tw * c.th), dim3(256), 0, st, f);
+    const unsigned tiles = (unsigned)(c.tw * c.th);
+    (void)max_len_hint;
+    hipLaunchKernelGGL(k_sort_lds<kSortSmall>, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, 0);
+    hipLaunchKernelGGL(k_sort_lds<kSortLarge>, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, kSortSmall);
+    hipLaunchKernelGGL(k_sort_global, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, kSortLarge);
 }
 
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,

@@ -3,10 +3,14 @@ import argparse
 import json
 import time
 
+import sys
+from pathlib import Path
+
 import numpy as np
 import torch
 
-from sim_a_splat_amd.rasterizer import Rasterizer
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from sim_a_splat_amd.rasterizer import Rasterizer  # noqa: E402
 from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, config_scene_and_cameras
 
 ap = argparse.ArgumentParser()
