@@ -45,7 +45,7 @@ struct sas_ctx {
     bool has_scene = false;
     std::vector<float> group_host;
     // frame scratch
-    DevBuf rec, info, tilebuf, keys, ids, counters;
+    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
     long long cap = 0;
     int tiles_alloc = 0;
     unsigned *stats_host = nullptr;  // pinned, 8 words
@@ -192,6 +192,9 @@ SasFrame frame_of(sas_ctx *c, int tiles)
     f.keys = (unsigned long long *)c->keys.p;
     f.sorted_ids = (int *)c->ids.p;
     f.cap = c->cap;
+    f.wg_vis = (int *)c->wgvis.p;
+    f.tile_max = (unsigned *)c->tilemax.p;
+    f.n_wg = (int)((c->scene.n + 255) / 256);
     return f;
 }
 
@@ -209,6 +212,8 @@ int enqueue_frame(sas_ctx *c)
     size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
     cbytes = (cbytes + 15) & ~(size_t)15;
     if ((rc = ensure(c, c->counters, cbytes))) return rc;
+    if ((rc = ensure(c, c->wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
+    if ((rc = ensure(c, c->tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if (c->cap == 0) {
         long long want = 4 * (long long)n;
         if (want < (1ll << 20)) want = 1ll << 20;
@@ -238,8 +243,9 @@ int enqueue_frame(sas_ctx *c)
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     sas_launch_sort(st, c->scene, cam, f, c->stats[SAS_S_MAX_TILE_LEN]);
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0);
-    if (a.depth && (a.flags & SAS_DEPTH_FILL_MAX)) sas_launch_depth_fill(st, cam, f, a.depth);
+    const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
+    sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0, fill);
+    if (fill) sas_launch_depth_fill(st, cam, f, a.depth);
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[5], st));
     c->ev_valid = timing;
     HIP_TRY(c, hipGetLastError());
@@ -306,7 +312,7 @@ int sas_destroy(sas_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->pending) (void)hipStreamSynchronize(c->last.stream);
     for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
-                      &c->counters})
+                      &c->counters, &c->wgvis, &c->tilemax})
         release(*b);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->ev_made)

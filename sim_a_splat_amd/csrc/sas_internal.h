@@ -51,6 +51,9 @@ struct SasFrame {
     int *sorted_ids;           // [cap]
     long long cap;
     unsigned *stats;           // [8]
+    int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup
+    unsigned *tile_max;        // [tiles] per-tile max expected depth (bits), written when depth is filled
+    int n_wg;
 };
 
 struct SasOutputs {
@@ -69,5 +72,5 @@ void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
 void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint);
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
-                      bool fast_exp);
+                      bool fast_exp, bool want_max);
 void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth);

@@ -5,7 +5,8 @@
 //                      48-byte projected record, tile rectangle, per-tile counts
 //   k_scan      T5     exclusive scan of the per-tile counts (tile_offset, scatter cursors)
 //   k_scatter   T3     (depth bits | index) keys into per-tile segments
-//   k_sort      T4     per-tile sort in LDS (replaces the global 64-bit radix sort)
+//   k_sort      T4     per-tile stable LSD radix sort on depth bits in LDS, wave-ballot ranks
+//                      (replaces the global 64-bit radix sort)
 //   k_blend     T6+T0  one wave per 16x16 tile, 4 pixels per lane, LDS-staged splat queue,
 //                      wave-uniform skip per 8x8 quadrant, front-to-back compositing,
 //                      background / clamp / uint8 / expected-depth epilogue
@@ -408,8 +409,15 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, SasCam c, SasFrame 
     }
     for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, c.tw, 0u, 0u,
                   [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
+    // visible count: one plain store per workgroup (a same-address atomic per wave would
+    // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
+    __shared__ int s_nvis;
+    if (threadIdx.x == 0) s_nvis = 0;
+    __syncthreads();
     const unsigned long long vb = __ballot(vis);
-    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&f.stats[0], (unsigned)__popcll(vb));
+    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis, (int)__popcll(vb));
+    __syncthreads();
+    if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = s_nvis;
 }
 
 // ---- k_scan: exclusive scan over tiles (one workgroup) ------------------------------------------
@@ -442,9 +450,17 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
     }
+    int nvis = 0;
+    for (int i = tid; i < f.n_wg; i += 1024) nvis += f.wg_vis[i];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d));
-    if (lane == 0) atomicMax(&f.stats[4], (unsigned)maxlen);
+    for (int d = 32; d > 0; d >>= 1) {
+        maxlen = max(maxlen, __shfl_xor(maxlen, d));
+        nvis += __shfl_xor(nvis, d);
+    }
+    if (lane == 0) {
+        atomicMax(&f.stats[4], (unsigned)maxlen);
+        if (nvis) atomicAdd(&f.stats[0], (unsigned)nvis);
+    }
     if (tid == 0) {
         const int total = carry_s;
         f.tile_offset[tiles] = total;
@@ -501,15 +517,24 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame 
 }
 
 // ---- k_sort: per-tile ascending sort of 64-bit keys ---------------------------------------------
-// Three size classes are launched over all tiles; a workgroup whose tile is not in its class
-// exits at once.  LDS classes use a bitonic network on (depth bits, caller index) keys, which are
-// unique, so any correct sort reproduces the stable radix order of the reference.  The sorted
-// caller indices are translated to storage slots (inv_perm) on the way out.
-template <int CAP>
-__global__ __launch_bounds__(256) void k_sort_lds(SasFrame f, const int *inv_perm, int lo_excl)
+// Size classes are launched over all tiles; a workgroup whose tile is not in its class exits at
+// once.  The LDS classes run a stable LSD radix sort (8-bit digits) over the depth word only,
+// skipping bytes that do not vary inside the tile, then order the rare runs of identical depth by
+// the caller's Gaussian index: the result equals the reference's stable sort of
+// (tile | depth bits) keys emitted in index order.  Stable ranks come from wave ballots, not LDS
+// atomics.  Sorted caller indices are translated to storage slots (inv_perm) on the way out.
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *inv_perm, int lo_excl)
 {
-    __shared__ unsigned long long sk[CAP];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    constexpr int W = THREADS / 64;     // waves
+    constexpr int NB = CAP / THREADS;   // 64-key batches per wave
+    static_assert(THREADS >= 256 && CAP % THREADS == 0, "radix sort geometry");
+    __shared__ unsigned long long bufA[CAP], bufB[CAP];
+    __shared__ unsigned cnt[W][256];
+    __shared__ unsigned s_dbase[256];
+    __shared__ unsigned s_wsum[4];
+    __shared__ unsigned s_or, s_and;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long beg = f.tile_offset[t];
     long long end = f.tile_offset[t + 1];
     if (end > f.cap) end = f.cap;
@@ -521,23 +546,114 @@ __global__ __launch_bounds__(256) void k_sort_lds(SasFrame f, const int *inv_per
         if (tid == 0) out[0] = inv_perm[(unsigned)g[0]];
         return;
     }
-    int P = 2;
-    while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 256) sk[i] = (i < n) ? g[i] : ~0ull;
+    if (tid == 0) { s_or = 0u; s_and = ~0u; }
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < (P >> 1); p += 256) {
-                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int r = l | j;
-                const bool asc = (l & k) == 0;
-                const unsigned long long a = sk[l], b = sk[r];
-                if ((a > b) == asc) { sk[l] = b; sk[r] = a; }
+    const int base = wv * (NB * 64) + lane;   // element index of batch b: base + 64 b
+    unsigned long long k[NB];
+    unsigned orv = 0u, andv = ~0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = base + 64 * b;
+        k[b] = (i < n) ? g[i] : ~0ull;
+        if (i < n) { orv |= (unsigned)(k[b] >> 32); andv &= (unsigned)(k[b] >> 32); }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { orv |= __shfl_xor(orv, d); andv &= __shfl_xor(andv, d); }
+    if (lane == 0) { atomicOr(&s_or, orv); atomicAnd(&s_and, andv); }
+    __syncthreads();
+    const unsigned vary = s_or ^ s_and;
+    unsigned long long *src = bufA, *dst = bufB;
+    bool first = true;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int byte = 0; byte < 4; ++byte) {
+        if (((vary >> (8 * byte)) & 0xffu) == 0u) continue;   // uniform
+        if (!first) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = base + 64 * b;
+                k[b] = (i < n) ? src[i] : ~0ull;
             }
-            __syncthreads();
+        }
+        for (int d = lane; d < 256; d += 64) cnt[wv][d] = 0u;
+        unsigned rank[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = base + 64 * b;
+            const bool act = i < n;
+            const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
+            unsigned long long m = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool on = (d >> bit) & 1u;
+                const unsigned long long bm = __ballot(on);
+                m &= on ? bm : ~bm;
+            }
+            const unsigned below = (unsigned)__popcll(m & lt_mask);
+            const unsigned total = (unsigned)__popcll(m);
+            const unsigned prev = act ? cnt[wv][d] : 0u;
+            if (act && below == 0u) cnt[wv][d] = prev + total;
+            rank[b] = prev + below;
+        }
+        __syncthreads();
+        unsigned tot = 0u, incl = 0u;
+        if (tid < 256) {
+            unsigned run = 0u;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { const unsigned cc = cnt[w][tid]; cnt[w][tid] = run; run += cc; }
+            tot = run;
+            incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned off = incl - tot;
+            for (int w = 0; w < wv; ++w) off += s_wsum[w];
+            s_dbase[tid] = off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = base + 64 * b;
+            if (i < n) {
+                const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
+                dst[s_dbase[d] + cnt[wv][d] + rank[b]] = k[b];
+            }
+        }
+        __syncthreads();
+        unsigned long long *tmp = src; src = dst; dst = tmp;
+        first = false;
+    }
+    if (first) {   // every depth identical: keys are still only in registers
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = base + 64 * b;
+            if (i < n) src[i] = k[b];
+        }
+        __syncthreads();
+    }
+    // runs of identical depth bits: order by caller index (the run's first element does it;
+    // the depth words other threads look at do not change under the permutation)
+    for (int i = tid; i < n; i += THREADS) {
+        const unsigned hd = (unsigned)(src[i] >> 32);
+        const bool lead = (i == 0 || (unsigned)(src[i - 1] >> 32) != hd) && (i + 1 < n) && (unsigned)(src[i + 1] >> 32) == hd;
+        if (lead) {
+            int j = i + 1;
+            while (j < n && (unsigned)(src[j] >> 32) == hd) ++j;
+            for (int a = i + 1; a < j; ++a) {
+                const unsigned long long v = src[a];
+                int q = a - 1;
+                while (q >= i && src[q] > v) { src[q + 1] = src[q]; --q; }
+                src[q + 1] = v;
+            }
         }
     }
-    for (int i = tid; i < n; i += 256) out[i] = inv_perm[(unsigned)sk[i]];
+    __syncthreads();
+    for (int i = tid; i < n; i += THREADS) out[i] = inv_perm[(unsigned)src[i]];
 }
 
 // Lists longer than the largest LDS class: same network in its all-ascending form (the first
@@ -632,7 +748,7 @@ DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, floa
     }
 }
 
-template <bool FAST_EXP>
+template <bool FAST_EXP, bool WANT_MAX>
 __global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o, long long n_gauss)
 {
     __shared__ float4 q0[64], q1[64], q2[64];
@@ -719,15 +835,26 @@ __global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o
     finish(p10, in10, ix1, iy0);
     finish(p01, in01, ix0, iy1);
     finish(p11, in11, ix1, iy1);
+    if (WANT_MAX) {
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
-    if (lane == 0 && maxed > 0.0f) atomicMax(&f.stats[3], __float_as_uint(maxed));
+        for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
+        if (lane == 0) f.tile_max[tile] = __float_as_uint(maxed);   // reduced by k_depth_fill
+    }
 }
 
 // depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
-__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *stats, float *depth, long long npix)
+// Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
+// no same-address atomics.  ED >= 0, so the float order is the order of the bit patterns.
+__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *tile_max, int tiles, float *depth, long long npix)
 {
-    const float mx = __uint_as_float(stats[3]);
+    __shared__ unsigned s_max[4];
+    unsigned m = 0;
+    for (int t = threadIdx.x; t < tiles; t += 256) m = max(m, tile_max[t]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
         if (depth[p] == 0.0f) depth[p] = mx;
 }
@@ -771,24 +898,29 @@ void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, cons
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, c, f);
 }
 
-constexpr int kSortSmall = 1024, kSortLarge = 8192;
+constexpr int kSortSmall = 2048, kSortLarge = 8192;
 
 void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint)
 {
     const unsigned tiles = (unsigned)(c.tw * c.th);
     (void)max_len_hint;
-    hipLaunchKernelGGL(k_sort_lds<kSortSmall>, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, 0);
-    hipLaunchKernelGGL(k_sort_lds<kSortLarge>, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, kSortSmall);
+    hipLaunchKernelGGL((k_sort_radix<kSortSmall, 256>), dim3(tiles), dim3(256), 0, st, f, s.inv_perm, 0);
+    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024>), dim3(tiles), dim3(1024), 0, st, f, s.inv_perm, kSortSmall);
     hipLaunchKernelGGL(k_sort_global, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, kSortLarge);
 }
 
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
-                      bool fast_exp)
+                      bool fast_exp, bool want_max)
 {
     const unsigned grid = (unsigned)(c.tw * c.th);
     const long long n = s.n > 0 ? s.n : 1;
-    if (fast_exp) hipLaunchKernelGGL(k_blend<true>, dim3(grid), dim3(64), 0, st, c, f, o, n);
-    else hipLaunchKernelGGL(k_blend<false>, dim3(grid), dim3(64), 0, st, c, f, o, n);
+    if (fast_exp) {
+        if (want_max) hipLaunchKernelGGL((k_blend<true, true>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+        else hipLaunchKernelGGL((k_blend<true, false>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+    } else {
+        if (want_max) hipLaunchKernelGGL((k_blend<false, true>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+        else hipLaunchKernelGGL((k_blend<false, false>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+    }
 }
 
 void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth)
@@ -796,5 +928,5 @@ void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, f
     const long long npix = (long long)c.W * c.H;
     unsigned grid = (unsigned)((npix + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_depth_fill, dim3(grid), dim3(256), 0, st, (const unsigned *)f.stats, depth, npix);
+    hipLaunchKernelGGL(k_depth_fill, dim3(grid), dim3(256), 0, st, (const unsigned *)f.tile_max, c.tw * c.th, depth, npix);
 }

@@ -149,3 +149,31 @@ def test_fast_exp_delta_is_small_but_not_the_contract(rasterizer):
     d = np.abs(a - b)
     # v_exp_f32 differs in the last bits; away from threshold flips the image moves by < 1e-5
     assert np.quantile(d, 0.999) < 1e-5
+
+
+def test_depth_ties_order_by_caller_index(rasterizer):
+    """Thousands of splats on a few constant-depth planes: the sort sees long runs of identical depth
+    bits and must order them by the caller's index (stable radix order of the reference)."""
+    rng = np.random.default_rng(3)
+    sc = make_scene(6000, seed=71, log_scale_mean=float(np.log(0.05)))
+    sc.means[:, 2] = rng.choice(np.array([0.0, 0.25, 0.5], np.float32), size=sc.n)   # camera looks down -z
+    sc.means[:, :2] *= 0.4
+    sc.opacities[:] = np.clip(sc.opacities, 0.05, 0.5)
+    cam = ring_camera(128, 96, 110.0)          # yaw 0: depth = 3 - z exactly
+    _upload(rasterizer, sc)
+    _, ref = _compare(rasterizer, sc, cam)
+    assert len(np.unique(ref["depths"][(ref["radii"] > 0).all(1)])) <= 3
+    tl = rasterizer.read_tile_lists(cam.tiles)
+    assert np.array_equal(tl["sorted_ids"], ref["sorted_ids"])
+
+
+def test_mid_size_lists_use_the_large_lds_class(rasterizer):
+    """Per-tile lists between 2048 and 8192 entries (second sort class)."""
+    rng = np.random.default_rng(10)
+    sc = make_scene(5000, seed=81, log_scale_mean=float(np.log(0.004)))
+    sc.means[:] = rng.normal(0, 0.012, size=sc.means.shape).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.02, 0.15)
+    cam = ring_camera(96, 80, 100.0)
+    _upload(rasterizer, sc)
+    _compare(rasterizer, sc, cam)
+    assert 2048 < rasterizer.stats()["max_tile_len"] <= 8192
