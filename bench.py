@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered frames/s at 1M Gaussians, 1920x1080 (BASELINE.json config 3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (project + SH, bin, per-tile sort, blend) over one synthetic
+1M-Gaussian scene resident in HBM, one 1080p view per GPU, float32 RGB out.  With N > 1 every
+rank renders its own view of the replicated scene (weak scaling) and the finished
+frames are gathered to rank 0 over RCCL, one frame behind the renderer.  Rank 0 prints ONE JSON
+line.  The oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from sim_a_splat_amd import distributed as sdist  # noqa: E402
+from sim_a_splat_amd.rasterizer import Rasterizer  # noqa: E402
+from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, make_scene, ring_camera  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(n, n_vis, m, w, h, out_bytes_per_pixel=12):
+    """N*236 + N_vis*44 + M*60 + W*H*out."""
+    return n * 236 + n_vis * 44 + m * 60 + w * h * out_bytes_per_pixel
+
+
+def blend_bytes(m, w, h, out_bytes_per_pixel=12):
+    """Dominant kernel (k_blend): gather of M sorted entries (id 4 B + record 40 B) + the frame."""
+    return m * 44 + w * h * out_bytes_per_pixel
+
+
+def cpu_baseline(scene, cam, budget_s=20.0):
+    import oracle
+    threads = oracle.num_threads()
+    kw = dict(quats=scene.quats, scales=scene.scales, sh_degree=3, background=NERFSTUDIO_EVAL_BACKGROUND)
+    t0 = time.perf_counter()
+    oracle.render(scene.means, scene.opacities, scene.sh, cam.viewmat, cam.K, cam.width, cam.height, **kw)
+    first = time.perf_counter() - t0
+    times = []
+    while len(times) < 10 and (sum(times) + first) < budget_s or len(times) < 2:
+        t0 = time.perf_counter()
+        oracle.render(scene.means, scene.opacities, scene.sh, cam.viewmat, cam.K, cam.width, cam.height, **kw)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full frames of the same workload after 1 warm-up (median), C oracle with "
+                      f"OpenMP on {threads} threads of {os.cpu_count()} host CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local_rank = sdist.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H = 1920, 1080
+    scene = make_scene(a.gaussians, seed=3, log_scale_mean=float(np.log(0.006)))
+    cam = ring_camera(W, H, 1000.0, yaw_deg=45.0 * rank)   # one independent view per GPU
+    r = Rasterizer(dev)
+    r.upload(scene.means, scene.opacities, scene.sh, quats=scene.quats, scales=scene.scales, sh_degree=3)
+    bufs = [{"rgb": torch.empty((H, W, 3), dtype=torch.float32, device=dev)} for _ in range(3)]
+    gather = sdist.FrameGather(world, rank)
+
+    def step(i, timing):
+        out = bufs[i % 3]
+        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=out, block=False,
+                 timing=timing)
+        if world > 1:
+            gather.start(out["rgb"])   # behind this frame on the stream; overlaps the next render
+
+    def sync():
+        r.wait()
+        gather.finish()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for i in range(a.warmup):
+        step(i, False)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = r.stats()
+
+    # dominant-kernel duration: HIP events recorded by the C ABI on the launch stream around
+    # every stage (SAS_TIMING); timed frames run unpipelined, so they are measured after the
+    # throughput loop over the same number of frames
+    blend_ms, stage = [], {}
+    for i in range(max(10, min(a.steps, 50))):
+        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=bufs[0], timing=True)
+        tms = r.stage_times()
+        blend_ms.append(tms["blend"])
+        for k, v in tms.items():
+            stage.setdefault(k, []).append(v)
+    blend_s = float(np.mean(blend_ms)) * 1e-3
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        fps = world * a.steps / elapsed
+        achieved = blend_bytes(st["n_isect"], W, H) / blend_s / 1e9
+        frame_bytes = algorithmic_bytes(scene.n, st["n_visible"], st["n_isect"], W, H)
+        line = {
+            "metric": "rendered frames/sec at 1M Gaussians 1920x1080",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 1M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, "
+                                   "fx=fy=1000, one view per GPU, float32 RGB out",
+                       "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
+                       "views_per_step": world, "parallelism": f"views{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": blend_s * 1e3,
+                         "frame_algorithmic_GBps": frame_bytes / (elapsed / a.steps) / 1e9,
+                         "frame_frac": frame_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS,
+                         "stage_ms": {k: float(np.mean(v)) for k, v in stage.items()}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, cam)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,17 @@ struct RenderArgs {
 
 }  // namespace
 
+// One in-flight frame.  Two slots let the host enqueue frame i+1 before it verifies frame i
+// (overflow flag, stats), so an SAS_ASYNC caller keeps the GPU busy without ever consuming an
+// unverified frame: sas_render returns only after the frame before the previous one is verified.
+struct Slot {
+    RenderArgs args;
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[SAS_T_COUNT + 1] = {};
+    unsigned *stats_host = nullptr;  // pinned, 8 words
+    bool busy = false, timed = false;
+};
+
 struct sas_ctx {
     int device = 0;
     std::string err;
@@ -44,19 +55,18 @@ struct sas_ctx {
     SasScene scene{};
     bool has_scene = false;
     std::vector<float> group_host;
-    // frame scratch
+    // frame scratch (shared by the in-flight frames: they are ordered by the stream)
     DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
     long long cap = 0;
-    int tiles_alloc = 0;
-    unsigned *stats_host = nullptr;  // pinned, 8 words
-    // last frame
-    RenderArgs last;
+    // frames
+    Slot slots[2];
+    int head = 0;        // oldest busy slot
+    int inflight = 0;
+    hipStream_t stream = nullptr;   // stream of the in-flight frames
+    RenderArgs last;     // most recently enqueued frame (parity hooks)
     SasCam cam{};
-    bool pending = false;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
-    hipEvent_t ev[SAS_T_COUNT + 1] = {};
-    bool ev_made = false, ev_valid = false;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -198,87 +208,108 @@ SasFrame frame_of(sas_ctx *c, int tiles)
     return f;
 }
 
-int enqueue_frame(sas_ctx *c)
+int enqueue_frame(sas_ctx *c, Slot &sl)
 {
-    const RenderArgs &a = c->last;
+    const RenderArgs &a = sl.args;
     make_cam(a.viewmat, a.K, a.W, a.H, c->cam);
     const SasCam &cam = c->cam;
     const int tiles = cam.tw * cam.th;
     const int64_t n = c->scene.n;
     int rc;
-    if ((rc = ensure(c, c->rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, c->info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, c->tilebuf, sizeof(int) * (size_t)(2 * tiles + 2)))) return rc;
+    const size_t need_tiles = sizeof(int) * (size_t)(2 * tiles + 2);
     size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
     cbytes = (cbytes + 15) & ~(size_t)15;
-    if ((rc = ensure(c, c->counters, cbytes))) return rc;
-    if ((rc = ensure(c, c->wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
-    if ((rc = ensure(c, c->tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if (c->cap == 0) {
         long long want = 4 * (long long)n;
         if (want < (1ll << 20)) want = 1ll << 20;
         c->cap = want;
     }
+    const bool realloc_needed =
+        c->rec.bytes < sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1) || c->tilebuf.bytes < need_tiles ||
+        c->counters.bytes < cbytes || c->keys.bytes < sizeof(unsigned long long) * (size_t)c->cap ||
+        c->tilemax.bytes < sizeof(unsigned) * (size_t)tiles || !c->wgvis.p || !c->info.p || !c->ids.p;
+    if (realloc_needed && c->inflight > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // scratch is shared
+    if ((rc = ensure(c, c->rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, c->info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, c->tilebuf, need_tiles))) return rc;
+    if ((rc = ensure(c, c->counters, cbytes))) return rc;
+    if ((rc = ensure(c, c->wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
+    if ((rc = ensure(c, c->tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if ((rc = ensure(c, c->keys, sizeof(unsigned long long) * (size_t)c->cap))) return rc;
     if ((rc = ensure(c, c->ids, sizeof(int) * (size_t)c->cap))) return rc;
 
     hipStream_t st = a.stream;
     const bool timing = (a.flags & SAS_TIMING) != 0;
-    if (timing && !c->ev_made) {
-        for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
-        c->ev_made = true;
-    }
     SasFrame f = frame_of(c, tiles);
     SasOutputs o{};
     o.rgb = a.rgb; o.alpha = a.alpha; o.depth = a.depth; o.rgb8 = a.rgb8;
     o.bg[0] = a.bg[0]; o.bg[1] = a.bg[1]; o.bg[2] = a.bg[2];
 
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
     HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, cbytes, st));
     sas_launch_project(st, c->scene, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
     sas_launch_scan(st, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
     sas_launch_scatter(st, c->scene, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
     sas_launch_sort(st, c->scene, cam, f, c->stats[SAS_S_MAX_TILE_LEN]);
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
     sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0, fill);
     if (fill) sas_launch_depth_fill(st, cam, f, a.depth);
-    if (timing) HIP_TRY(c, hipEventRecord(c->ev[5], st));
-    c->ev_valid = timing;
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
+    sl.timed = timing;
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->stats_host, c->counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    c->pending = true;
+    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, c->counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(sl.done, st));
+    sl.busy = true;
+    c->last = a;
     return SAS_OK;
 }
 
-int finish_frame(sas_ctx *c)
+// Verify the oldest in-flight frame; on overflow grow the intersection buffer and render it again.
+int complete_oldest(sas_ctx *c)
 {
+    if (c->inflight <= 0) return SAS_OK;
+    Slot &sl = c->slots[c->head];
     for (int attempt = 0; attempt < 4; ++attempt) {
-        HIP_TRY(c, hipStreamSynchronize(c->last.stream));
-        c->pending = false;
-        const unsigned *s = c->stats_host;
+        HIP_TRY(c, hipEventSynchronize(sl.done));
+        const unsigned *s = sl.stats_host;
         c->stats[SAS_S_NVISIBLE] = s[0];
         c->stats[SAS_S_NISECT] = s[1];
         c->stats[SAS_S_MAX_TILE_LEN] = s[4];
         c->stats[SAS_S_CAPACITY] = c->cap;
         c->stats[SAS_S_REGROWS] = c->regrows;
         c->stats[SAS_S_WINDOW_MISSES] = s[5];
-        if (c->ev_valid) {
-            for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], c->ev[k], c->ev[k + 1]);
-            (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], c->ev[0], c->ev[5]);
+        if (sl.timed) {
+            for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
+            (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[5]);
         }
-        if (!s[2]) return SAS_OK;
-        // intersection buffer too small: grow to the measured need (+25 %) and render again
-        long long need = (long long)s[1];
-        c->cap = need + need / 4 + 1024;
+        if (!s[2]) {
+            sl.busy = false;
+            c->head ^= 1;
+            c->inflight--;
+            return SAS_OK;
+        }
+        // intersection buffer too small: drain the stream, grow to the measured need (+25 %), re-render
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const long long need = (long long)s[1];
+        if (need + need / 4 + 1024 > c->cap) c->cap = need + need / 4 + 1024;
         c->regrows++;
-        int rc = enqueue_frame(c);
+        int rc = enqueue_frame(c, sl);
         if (rc) return rc;
     }
     return fail(c, SAS_ERR_HIP, "intersection buffer kept overflowing");
+}
+
+int complete_all(sas_ctx *c)
+{
+    while (c->inflight > 0) {
+        int rc = complete_oldest(c);
+        if (rc) return rc;
+    }
+    return SAS_OK;
 }
 
 }  // namespace
@@ -297,11 +328,17 @@ int sas_create(int device, sas_ctx **out)
     sas_ctx *c = new (std::nothrow) sas_ctx();
     if (!c) return SAS_ERR_OOM;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&c->stats_host, 8 * sizeof(unsigned)) != hipSuccess) {
-        delete c;
+    bool ok = hipSetDevice(device) == hipSuccess;
+    for (Slot &sl : c->slots) {
+        ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
+        ok = ok && hipEventCreate(&sl.done) == hipSuccess;
+        for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        if (ok) memset(sl.stats_host, 0, 8 * sizeof(unsigned));
+    }
+    if (!ok) {
+        sas_destroy(c);
         return SAS_ERR_HIP;
     }
-    memset(c->stats_host, 0, 8 * sizeof(unsigned));
     *out = c;
     return SAS_OK;
 }
@@ -310,13 +347,16 @@ int sas_destroy(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->pending) (void)hipStreamSynchronize(c->last.stream);
+    if (c->inflight > 0) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
                       &c->counters, &c->wgvis, &c->tilemax})
         release(*b);
-    if (c->stats_host) (void)hipHostFree(c->stats_host);
-    if (c->ev_made)
-        for (auto &e : c->ev) (void)hipEventDestroy(e);
+    for (Slot &sl : c->slots) {
+        if (sl.stats_host) (void)hipHostFree(sl.stats_host);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        for (auto &e : sl.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete c;
     return SAS_OK;
 }
@@ -336,8 +376,10 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     if (n_groups < 0 || n_groups > 256) return fail(c, SAS_ERR_INVALID, "n_groups %d out of [0,256]", n_groups);
     if (group_id && n_groups <= 0) return fail(c, SAS_ERR_INVALID, "group_id given but n_groups == 0");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) HIP_TRY(c, hipStreamSynchronize(c->last.stream));
-    c->pending = false;
+    {
+        int rcw = complete_all(c);
+        if (rcw) return rcw;
+    }
     c->has_scene = false;
 
     const int deg = sh_degree < 0 ? -1 : sh_degree;
@@ -431,14 +473,14 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
     if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
     if (n_groups != c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "scene has %d groups, got %d", c->scene.n_groups, n_groups);
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) {
-        int rc = finish_frame(c);
+    {
+        int rc = complete_all(c);   // in-flight frames may still have to be re-rendered with the old poses
         if (rc) return rc;
     }
     c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
     // stream-ordered behind earlier frames of the same stream; the host copy is ours
     HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice,
-                              c->last.valid ? c->last.stream : nullptr));
+                              c->stream));
     return SAS_OK;
 }
 
@@ -452,30 +494,38 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
         return fail(c, SAS_ERR_INVALID, "bad image size %dx%d", width, height);
     if (!(K[0] > 0.0f) || !(K[4] > 0.0f)) return fail(c, SAS_ERR_INVALID, "focal lengths must be positive");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) {
-        int rc = finish_frame(c);
+    hipStream_t st = (hipStream_t)stream;
+    if (c->inflight > 0 && (st != c->stream || (flags & SAS_TIMING))) {
+        int rc = complete_all(c);   // one stream at a time; timed frames run alone
         if (rc) return rc;
     }
-    RenderArgs &a = c->last;
+    if (c->inflight == 2) {
+        int rc = complete_oldest(c);
+        if (rc) return rc;
+    }
+    c->stream = st;
+    Slot &sl = c->slots[(c->head + c->inflight) & 1];
+    RenderArgs &a = sl.args;
     memcpy(a.viewmat, viewmat, sizeof(a.viewmat));
     memcpy(a.K, K, sizeof(a.K));
     for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
     a.W = width; a.H = height; a.flags = flags;
     a.rgb = rgb; a.alpha = alpha; a.depth = depth; a.rgb8 = rgb8;
-    a.stream = (hipStream_t)stream;
+    a.stream = st;
     a.valid = true;
-    int rc = enqueue_frame(c);
+    int rc = enqueue_frame(c, sl);
     if (rc) return rc;
+    c->inflight++;
     if (flags & SAS_ASYNC) return SAS_OK;
-    return finish_frame(c);
+    return complete_all(c);
 }
 
 int sas_wait(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
-    if (!c->pending) return SAS_OK;
+    if (c->inflight <= 0) return SAS_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    return finish_frame(c);
+    return complete_all(c);
 }
 
 int sas_stage_times(sas_ctx *c, float *ms, int n)
@@ -497,8 +547,8 @@ int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depth
     if (!c) return SAS_ERR_INVALID;
     if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) {
-        int rc = finish_frame(c);
+    {
+        int rc = complete_all(c);
         if (rc) return rc;
     }
     const int64_t n = c->scene.n;
@@ -527,8 +577,8 @@ int sas_read_tile_lists(sas_ctx *c, int32_t *tile_offsets, int32_t *sorted_ids, 
     if (!c) return SAS_ERR_INVALID;
     if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->pending) {
-        int rc = finish_frame(c);
+    {
+        int rc = complete_all(c);
         if (rc) return rc;
     }
     const int tiles = c->cam.tw * c->cam.th;

@@ -55,7 +55,7 @@ class Rasterizer:
             raise SasError(f"sas_create(device={self.device.index}) failed with status {rc}")
         self.n = 0
         self.n_groups = 0
-        self._keep = None  # outputs of an in-flight async frame
+        self._keep = []  # outputs of in-flight async frames (the C ABI keeps up to two)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -151,12 +151,12 @@ class Rasterizer:
                                 bg.ctypes.data_as(ctypes.c_void_p), flags, ptr("rgb"), ptr("alpha"), ptr("depth"),
                                 ptr("rgb8"), stream)
         self._check(rc, "sas_render")
-        self._keep = None if block else res
+        self._keep = [] if block else (self._keep + [res])[-2:]
         return res
 
     def wait(self) -> None:
         self._check(self._L.sas_wait(self._ctx), "sas_wait")
-        self._keep = None
+        self._keep = []
 
     # -- introspection ------------------------------------------------------------------------
     def stage_times(self) -> Dict[str, float]:
