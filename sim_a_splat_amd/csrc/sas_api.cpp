@@ -199,6 +199,7 @@ SasFrame frame_of(sas_ctx *c, int tiles)
     f.tile_count = (int *)c->counters.p + 8;
     f.tile_offset = (int *)c->tilebuf.p;
     f.tile_cursor = (int *)c->tilebuf.p + (tiles + 1);
+    f.tile_order = (int *)c->tilebuf.p + (2 * tiles + 1);
     f.keys = (unsigned long long *)c->keys.p;
     f.sorted_ids = (int *)c->ids.p;
     f.cap = c->cap;
@@ -216,7 +217,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     const int tiles = cam.tw * cam.th;
     const int64_t n = c->scene.n;
     int rc;
-    const size_t need_tiles = sizeof(int) * (size_t)(2 * tiles + 2);
+    const size_t need_tiles = sizeof(int) * (size_t)(3 * tiles + 2);
     size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
     cbytes = (cbytes + 15) & ~(size_t)15;
     if (c->cap == 0) {

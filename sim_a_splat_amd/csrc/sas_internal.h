@@ -47,8 +47,9 @@ struct SasFrame {
     int *tile_count;   // [tiles+1]
     int *tile_offset;  // [tiles+1]
     int *tile_cursor;  // [tiles]
-    unsigned long long *keys;  // [cap]  depth bits << 32 | gaussian index
-    int *sorted_ids;           // [cap]
+    int *tile_order;   // [tiles] tiles by descending list length (blend launch order)
+    unsigned long long *keys;  // [cap]  depth bits << 32 | caller index
+    int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
     unsigned *stats;           // [8]
     int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup

@@ -7,8 +7,9 @@
 //   k_scatter   T3     (depth bits | index) keys into per-tile segments
 //   k_sort      T4     per-tile stable LSD radix sort on depth bits in LDS, wave-ballot ranks
 //                      (replaces the global 64-bit radix sort)
-//   k_blend     T6+T0  one wave per 16x16 tile, 4 pixels per lane, LDS-staged splat queue,
-//                      wave-uniform skip per 8x8 quadrant, front-to-back compositing,
+//   k_blend     T6+T0  one workgroup per 16x16 tile (longest list first), one wave per 8x8
+//                      quadrant, LDS-staged splat queue compacted per wave by ballot from the
+//                      quadrant hit masks, front-to-back compositing,
 //                      background / clamp / uint8 / expected-depth epilogue
 //
 // ARITHMETIC CONTRACT: every value that reaches an output is produced by the same
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
 {
     __shared__ int wsum[16];
     __shared__ int carry_s;
+    __shared__ int s_bucket[33];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -449,6 +451,24 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         __syncthreads();
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
+    }
+    // blend launch order: tiles bucketed by floor(log2(length)), longest first, so that the long
+    // lists start early and the short ones fill the tail (order inside a bucket is irrelevant)
+    if (tid < 33) s_bucket[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < tiles; i += 1024) {
+        const int v = f.tile_count[i];
+        atomicAdd(&s_bucket[v ? 32 - __clz(v) : 0], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int bkt = 32; bkt >= 0; --bkt) { const int cnt = s_bucket[bkt]; s_bucket[bkt] = run; run += cnt; }
+    }
+    __syncthreads();
+    for (int i = tid; i < tiles; i += 1024) {
+        const int v = f.tile_count[i];
+        f.tile_order[atomicAdd(&s_bucket[v ? 32 - __clz(v) : 0], 1)] = i;
     }
     int nvis = 0;
     for (int i = tid; i < f.n_wg; i += 1024) nvis += f.wg_vis[i];
@@ -523,6 +543,9 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame 
 // the caller's Gaussian index: the result equals the reference's stable sort of
 // (tile | depth bits) keys emitted in index order.  Stable ranks come from wave ballots, not LDS
 // atomics.  Sorted caller indices are translated to storage slots (inv_perm) on the way out.
+// key low word = caller index  ->  list entry = storage slot
+DEV int entry_of(const int *inv_perm, unsigned lo) { return inv_perm[lo]; }
+
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *inv_perm, int lo_excl)
 {
@@ -543,19 +566,22 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
     const unsigned long long *g = f.keys + beg;
     int *out = f.sorted_ids + beg;
     if (n == 1) {
-        if (tid == 0) out[0] = inv_perm[(unsigned)g[0]];
+        if (tid == 0) out[0] = entry_of(inv_perm, (unsigned)g[0]);
         return;
     }
     if (tid == 0) { s_or = 0u; s_and = ~0u; }
     __syncthreads();
-    const int base = wv * (NB * 64) + lane;   // element index of batch b: base + 64 b
+    // contiguous chunk per wave, balanced over the waves: nbu batches of 64 keys each
+    const int nbu = (((n + W - 1) / W) + 63) >> 6;   // <= NB because n <= CAP
+    const int base = wv * (nbu * 64) + lane;          // element index of batch b: base + 64 b
     unsigned long long k[NB];
     unsigned orv = 0u, andv = ~0u;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int i = base + 64 * b;
-        k[b] = (i < n) ? g[i] : ~0ull;
-        if (i < n) { orv |= (unsigned)(k[b] >> 32); andv &= (unsigned)(k[b] >> 32); }
+        const bool in = b < nbu && i < n;
+        k[b] = in ? g[i] : ~0ull;
+        if (in) { orv |= (unsigned)(k[b] >> 32); andv &= (unsigned)(k[b] >> 32); }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { orv |= __shfl_xor(orv, d); andv &= __shfl_xor(andv, d); }
@@ -571,13 +597,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int i = base + 64 * b;
-                k[b] = (i < n) ? src[i] : ~0ull;
+                k[b] = (b < nbu && i < n) ? src[i] : ~0ull;
             }
         }
         for (int d = lane; d < 256; d += 64) cnt[wv][d] = 0u;
         unsigned rank[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            if (b >= nbu) break;   // uniform
             const int i = base + 64 * b;
             const bool act = i < n;
             const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int i = base + 64 * b;
-            if (i < n) {
+            if (b < nbu && i < n) {
                 const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
                 dst[s_dbase[d] + cnt[wv][d] + rank[b]] = k[b];
             }
@@ -632,7 +659,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int i = base + 64 * b;
-            if (i < n) src[i] = k[b];
+            if (b < nbu && i < n) src[i] = k[b];
         }
         __syncthreads();
     }
@@ -653,7 +680,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += THREADS) out[i] = inv_perm[(unsigned)src[i]];
+    for (int i = tid; i < n; i += THREADS) out[i] = entry_of(inv_perm, (unsigned)src[i]);
 }
 
 // Lists longer than the largest LDS class: same network in its all-ascending form (the first
@@ -693,14 +720,54 @@ __global__ __launch_bounds__(256) void k_sort_global(SasFrame f, const int *inv_
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += 256) out[i] = inv_perm[(unsigned)g[i]];
+    for (int i = tid; i < n; i += 256) out[i] = entry_of(inv_perm, (unsigned)g[i]);
 }
 
 // ---- k_blend: T6 + T0 epilogue -------------------------------------------------------------------
-// One wave per 16x16 tile.  Lane (lx,ly) in 8x8 owns the four pixels (lx+8qx, ly+8qy): the
-// quadratic form shares its per-column / per-row factors across them (24 VALU ops for 4 sigmas)
-// and each 8x8 quadrant gets its own wave-uniform skip.  A single wave executes its LDS
-// operations in order, so the staged queue needs no barrier.
+// One workgroup (4 waves) per 16x16 tile, launched longest list first.  Wave w owns the 8x8
+// quadrant w, one pixel per lane.  Per batch of 256 list entries every thread stages one 48-byte
+// record in LDS; each wave then ballots the entries whose quadrant mask names it into its own
+// compacted queue and walks only those, front to back.  A wave whose 64 pixels are all
+// terminated stops blending; the workgroup leaves when all four have.
+// Minimum of sigma(dx,dy) = 0.5 (A dx^2 + C dy^2) + B dx dy over a rectangle of pixel centres.
+// A convex quadratic whose centre lies outside the rectangle attains its minimum on an edge.
+DEV float min_sigma_rect(float mx, float my, float A, float B, float C, float nBoverC, float nBoverA,
+                         float xa, float xb, float ya, float yb)
+{
+    const float dxl = mx - xb, dxh = mx - xa, dyl = my - yb, dyh = my - ya;
+    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e ? dxh : dxl;
+        const float dy = fminf(fmaxf(nBoverC * dx, dyl), dyh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy);
+        const float ey = e ? dyh : dyl;
+        const float ex = fminf(fmaxf(nBoverA * ey, dxl), dxh);
+        best = fminf(best, 0.5f * (A * ex * ex + C * ey * ey) + B * ex * ey);
+    }
+    return best;
+}
+
+// 4-bit mask of the 8x8 quadrants of tile (tx,ty) that the Gaussian can reach.  Bit q = qx + 2 qy.
+// Computed by the thread that stages the record (one entry per thread, no divergence).
+// A quadrant is dropped only when sigma exceeds the blend stage's skip threshold by a margin
+// (0.05) four orders of magnitude above any rounding difference between this estimate and the
+// contract's per-pixel sigma, so dropping it never changes a pixel.
+DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B, float C, float nBoverC,
+                           float nBoverA, float thr)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xa = (float)(tx * SAS_TILE + (q & 1) * 8) + 0.5f;
+        const float ya = (float)(ty * SAS_TILE + (q >> 1) * 8) + 0.5f;
+        const float ms = min_sigma_rect(mx, my, A, B, C, nBoverC, nBoverA, xa, xa + 7.0f, ya, ya + 7.0f);
+        if (!(ms > thr + 0.05f)) m |= 1u << q;
+    }
+    return m;
+}
+
 struct PixState {
     float T, r, g, b, d;
     bool done;
@@ -749,73 +816,80 @@ DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, floa
 }
 
 template <bool FAST_EXP, bool WANT_MAX>
-__global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o, long long n_gauss)
+__global__ __launch_bounds__(256) void k_blend(SasCam c, SasFrame f, SasOutputs o, long long n_gauss)
 {
-    __shared__ float4 q0[64], q1[64], q2[64];
-    const int tile = blockIdx.x;
-    const int lane = threadIdx.x;
+    __shared__ float4 q0[256], q1[256], q2[256];
+    __shared__ unsigned s_mask[256];
+    __shared__ unsigned short s_queue[4][256];
+    __shared__ unsigned s_wmax[4];
+    const int tile = f.tile_order[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int ix0 = tx * SAS_TILE + lx, ix1 = ix0 + 8;
-    const int iy0 = ty * SAS_TILE + ly, iy1 = iy0 + 8;
-    const float px0 = (float)ix0 + 0.5f, px1 = (float)ix1 + 0.5f;
-    const float py0 = (float)iy0 + 0.5f, py1 = (float)iy1 + 0.5f;
-    const bool in00 = ix0 < c.W && iy0 < c.H, in10 = ix1 < c.W && iy0 < c.H;
-    const bool in01 = ix0 < c.W && iy1 < c.H, in11 = ix1 < c.W && iy1 < c.H;
-    PixState p00 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in00}, p10 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in10};
-    PixState p01 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in01}, p11 = {1.0f, 0.f, 0.f, 0.f, 0.f, !in11};
+    const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
+    const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
+    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const bool inside = ix < c.W && iy < c.H;
+    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
+    bool wdone = __all(p.done);   // wave-uniform
 
     const long long beg = f.tile_offset[tile];
     long long end = f.tile_offset[tile + 1];
     if (end > f.cap) end = f.cap;
 
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+    unsigned ment = 0u;
     auto fetch = [&](long long at) {
-        const long long idx = at + lane;
+        const long long idx = at + tid;
+        ment = 0u;
         if (idx < end) {
             long long id = (unsigned)f.sorted_ids[idx];
             if (id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
             ra = f.rec[3 * id + 0];
             rb = f.rec[3 * id + 1];
             rc = f.rec[3 * id + 2];
+            // approximate reciprocals are fine: the mask is conservative by a 0.05 margin in sigma
+            ment = quadrant_mask(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, -ra.w * __builtin_amdgcn_rcpf(rb.x),
+                                 -ra.w * __builtin_amdgcn_rcpf(ra.z), rb.z);
         }
     };
     if (beg < end) fetch(beg);
-    for (long long at = beg; at < end; at += 64) {
-        q0[lane] = ra; q1[lane] = rb; q2[lane] = rc;
-        __builtin_amdgcn_wave_barrier();
-        if (at + 64 < end) fetch(at + 64);   // next batch in flight while this one is blended
-        const int cnt = (int)((end - at) < 64 ? (end - at) : 64);
-        for (int k = 0; k < cnt; ++k) {
-            const float4 A = q0[k], B = q1[k], C = q2[k];
-            const float dx0 = A.x - px0, dx1 = A.x - px1;
-            const float dy0 = A.y - py0, dy1 = A.y - py1;
-            const float ax0 = (A.z * dx0) * dx0, ax1 = (A.z * dx1) * dx1;
-            const float cy0 = B.x * dy0, cy1 = B.x * dy1;
-            const float bx0 = A.w * dx0, bx1 = A.w * dx1;
-            const float s00 = fma_(0.5f, fma_(cy0, dy0, ax0), bx0 * dy0);
-            const float s10 = fma_(0.5f, fma_(cy0, dy0, ax1), bx1 * dy0);
-            const float s01 = fma_(0.5f, fma_(cy1, dy1, ax0), bx0 * dy1);
-            const float s11 = fma_(0.5f, fma_(cy1, dy1, ax1), bx1 * dy1);
-            const float thr = B.z;
-            const bool c00 = !p00.done && s00 >= 0.0f && s00 <= thr, c10 = !p10.done && s10 >= 0.0f && s10 <= thr;
-            const bool c01 = !p01.done && s01 >= 0.0f && s01 <= thr, c11 = !p11.done && s11 >= 0.0f && s11 <= thr;
-            if (__any(c00)) blend_one<FAST_EXP>(p00, c00, s00, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c10)) blend_one<FAST_EXP>(p10, c10, s10, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c01)) blend_one<FAST_EXP>(p01, c01, s01, B.y, C.x, C.y, C.z, B.w);
-            if (__any(c11)) blend_one<FAST_EXP>(p11, c11, s11, B.y, C.x, C.y, C.z, B.w);
-            if ((k & 15) == 15 && __all(p00.done && p10.done && p01.done && p11.done)) break;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (long long at = beg; at < end; at += 256) {
+        // the previous batch is fully consumed; leave once every wave has terminated
+        if (__syncthreads_and(wdone)) break;
+        q0[tid] = ra; q1[tid] = rb; q2[tid] = rc; s_mask[tid] = ment;
+        __syncthreads();
+        if (at + 256 < end) fetch(at + 256);   // next batch in flight while this one is blended
+        if (!wdone) {
+            const int cnt = (int)((end - at) < 256 ? (end - at) : 256);
+            int qn = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = j * 64 + lane;
+                const bool has = e < cnt && ((s_mask[e] >> wv) & 1u);
+                const unsigned long long m = __ballot(has);
+                if (has) s_queue[wv][qn + (int)__popcll(m & lt_mask)] = (unsigned short)e;
+                qn += (int)__popcll(m);
+            }
+            for (int k = 0; k < qn; ++k) {
+                const int e = s_queue[wv][k];
+                const float4 A = q0[e], B = q1[e], C = q2[e];
+                const float dx = A.x - px, dy = A.y - py;
+                const float sg = fma_(0.5f, fma_(B.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
+                const bool cand = !p.done && sg >= 0.0f && sg <= B.z;
+                if (__any(cand)) {
+                    blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
+                    if (__all(p.done)) break;
+                }
+            }
+            wdone = __all(p.done);
         }
-        if (__all(p00.done && p10.done && p01.done && p11.done)) break;
-        __builtin_amdgcn_wave_barrier();
     }
 
-    float maxed = 0.0f;
-    auto finish = [&](const PixState &p, bool inside, int ix, int iy) {
-        if (!inside) return;
+    float ED = 0.0f;
+    if (inside) {
         const float a = 1.0f - p.T;
-        const float ED = p.d / fmaxf(a, 1e-10f);
-        maxed = fmaxf(maxed, ED);
+        ED = p.d / fmaxf(a, 1e-10f);
         const long long pix = (long long)iy * c.W + ix;
         const float w = 1.0f - a;
         float v0 = p.r + w * o.bg[0], v1 = p.g + w * o.bg[1], v2 = p.b + w * o.bg[2];
@@ -830,15 +904,14 @@ __global__ __launch_bounds__(64) void k_blend(SasCam c, SasFrame f, SasOutputs o
             o.rgb8[3 * pix + 1] = (uint8_t)(int)floorf(fma_(v1, 255.0f, 0.5f));
             o.rgb8[3 * pix + 2] = (uint8_t)(int)floorf(fma_(v2, 255.0f, 0.5f));
         }
-    };
-    finish(p00, in00, ix0, iy0);
-    finish(p10, in10, ix1, iy0);
-    finish(p01, in01, ix0, iy1);
-    finish(p11, in11, ix1, iy1);
-    if (WANT_MAX) {
+    }
+    if (WANT_MAX) {   // uniform
+        float maxed = ED;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
-        if (lane == 0) f.tile_max[tile] = __float_as_uint(maxed);   // reduced by k_depth_fill
+        if (lane == 0) s_wmax[wv] = __float_as_uint(maxed);
+        __syncthreads();
+        if (tid == 0) f.tile_max[tile] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));   // reduced by k_depth_fill
     }
 }
 
@@ -915,11 +988,11 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const 
     const unsigned grid = (unsigned)(c.tw * c.th);
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
-        if (want_max) hipLaunchKernelGGL((k_blend<true, true>), dim3(grid), dim3(64), 0, st, c, f, o, n);
-        else hipLaunchKernelGGL((k_blend<true, false>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+        if (want_max) hipLaunchKernelGGL((k_blend<true, true>), dim3(grid), dim3(256), 0, st, c, f, o, n);
+        else hipLaunchKernelGGL((k_blend<true, false>), dim3(grid), dim3(256), 0, st, c, f, o, n);
     } else {
-        if (want_max) hipLaunchKernelGGL((k_blend<false, true>), dim3(grid), dim3(64), 0, st, c, f, o, n);
-        else hipLaunchKernelGGL((k_blend<false, false>), dim3(grid), dim3(64), 0, st, c, f, o, n);
+        if (want_max) hipLaunchKernelGGL((k_blend<false, true>), dim3(grid), dim3(256), 0, st, c, f, o, n);
+        else hipLaunchKernelGGL((k_blend<false, false>), dim3(grid), dim3(256), 0, st, c, f, o, n);
     }
 }
 
