@@ -35,16 +35,31 @@ struct RenderArgs {
 
 }  // namespace
 
-// One in-flight frame.  Two slots let the host enqueue frame i+1 before it verifies frame i
-// (overflow flag, stats), so an SAS_ASYNC caller keeps the GPU busy without ever consuming an
-// unverified frame: sas_render returns only after the frame before the previous one is verified.
+// Per-frame scratch.  Every slot owns one, so two frames can be on the GPU at the same time.
+struct Scratch {
+    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
+    long long cap = 0;
+};
+
+// One in-flight frame.  Each slot has its own internal stream (plus two side streams for the
+// concurrent sort classes) and its own scratch: the stages of a frame are each too short on
+// parallelism to fill 256 CUs (a few thousand tiles), so consecutive frames overlap on the chip.
+// The internal stream starts after everything the caller had enqueued on `stream` at the time of
+// sas_render; the caller's stream is made to wait for a frame when the NEXT frame is submitted
+// (or in sas_wait), which keeps exactly two frames in flight.
 struct Slot {
     RenderArgs args;
-    hipEvent_t done = nullptr;
+    hipStream_t fs = nullptr;
+    SasSortStreams sort_streams{};
+    hipEvent_t start = nullptr, done = nullptr;
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
     unsigned *stats_host = nullptr;  // pinned, 8 words
+    Scratch scr;
+    SasCam cam{};
     bool busy = false, timed = false;
 };
+
+constexpr int kSlots = 2;
 
 struct sas_ctx {
     int device = 0;
@@ -55,16 +70,13 @@ struct sas_ctx {
     SasScene scene{};
     bool has_scene = false;
     std::vector<float> group_host;
-    // frame scratch (shared by the in-flight frames: they are ordered by the stream)
-    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
-    long long cap = 0;
     // frames
-    Slot slots[2];
+    Slot slots[kSlots];
     int head = 0;        // oldest busy slot
     int inflight = 0;
-    hipStream_t stream = nullptr;   // stream of the in-flight frames
-    RenderArgs last;     // most recently enqueued frame (parity hooks)
-    SasCam cam{};
+    int last_slot = 0;   // most recently enqueued (parity hooks)
+    hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
+    bool has_frame = false;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -189,72 +201,72 @@ void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
     c.lim_y_neg = fmaf(0.3f, tan_fovy, c.cy / c.fy);
 }
 
-SasFrame frame_of(sas_ctx *c, int tiles)
+SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
 {
     SasFrame f{};
-    f.rec = (float4 *)c->rec.p;
-    f.info = (uint4 *)c->info.p;
+    f.rec = (float4 *)q.rec.p;
+    f.info = (uint4 *)q.info.p;
     // counters block: [stats 8 words][tile_count tiles+1]   (zeroed every frame by one memset)
-    f.stats = (unsigned *)c->counters.p;
-    f.tile_count = (int *)c->counters.p + 8;
-    f.tile_offset = (int *)c->tilebuf.p;
-    f.tile_cursor = (int *)c->tilebuf.p + (tiles + 1);
-    f.tile_order = (int *)c->tilebuf.p + (2 * tiles + 1);
-    f.keys = (unsigned long long *)c->keys.p;
-    f.sorted_ids = (int *)c->ids.p;
-    f.cap = c->cap;
-    f.wg_vis = (int *)c->wgvis.p;
-    f.tile_max = (unsigned *)c->tilemax.p;
+    f.stats = (unsigned *)q.counters.p;
+    f.tile_count = (int *)q.counters.p + 8;
+    f.tile_offset = (int *)q.tilebuf.p;
+    f.tile_cursor = (int *)q.tilebuf.p + (tiles + 1);
+    f.tile_order = (int *)q.tilebuf.p + (2 * tiles + 1);
+    f.sort_class = (int *)q.tilebuf.p + (3 * tiles + 1);
+    f.keys = (unsigned long long *)q.keys.p;
+    f.sorted_ids = (int *)q.ids.p;
+    f.cap = q.cap;
+    f.wg_vis = (int *)q.wgvis.p;
+    f.tile_max = (unsigned *)q.tilemax.p;
     f.n_wg = (int)((c->scene.n + 255) / 256);
     return f;
 }
 
+// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
 int enqueue_frame(sas_ctx *c, Slot &sl)
 {
     const RenderArgs &a = sl.args;
-    make_cam(a.viewmat, a.K, a.W, a.H, c->cam);
-    const SasCam &cam = c->cam;
+    make_cam(a.viewmat, a.K, a.W, a.H, sl.cam);
+    const SasCam &cam = sl.cam;
     const int tiles = cam.tw * cam.th;
     const int64_t n = c->scene.n;
+    Scratch &q = sl.scr;
     int rc;
-    const size_t need_tiles = sizeof(int) * (size_t)(3 * tiles + 2);
     size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
     cbytes = (cbytes + 15) & ~(size_t)15;
-    if (c->cap == 0) {
+    if (q.cap == 0) {
         long long want = 4 * (long long)n;
         if (want < (1ll << 20)) want = 1ll << 20;
-        c->cap = want;
+        q.cap = want;
     }
-    const bool realloc_needed =
-        c->rec.bytes < sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1) || c->tilebuf.bytes < need_tiles ||
-        c->counters.bytes < cbytes || c->keys.bytes < sizeof(unsigned long long) * (size_t)c->cap ||
-        c->tilemax.bytes < sizeof(unsigned) * (size_t)tiles || !c->wgvis.p || !c->info.p || !c->ids.p;
-    if (realloc_needed && c->inflight > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // scratch is shared
-    if ((rc = ensure(c, c->rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, c->info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, c->tilebuf, need_tiles))) return rc;
-    if ((rc = ensure(c, c->counters, cbytes))) return rc;
-    if ((rc = ensure(c, c->wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
-    if ((rc = ensure(c, c->tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
-    if ((rc = ensure(c, c->keys, sizeof(unsigned long long) * (size_t)c->cap))) return rc;
-    if ((rc = ensure(c, c->ids, sizeof(int) * (size_t)c->cap))) return rc;
+    if ((rc = ensure(c, q.rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(3 * tiles + 8)))) return rc;
+    if ((rc = ensure(c, q.counters, cbytes))) return rc;
+    if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
+    if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
+    if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
+    if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
 
-    hipStream_t st = a.stream;
+    hipStream_t st = sl.fs;
     const bool timing = (a.flags & SAS_TIMING) != 0;
-    SasFrame f = frame_of(c, tiles);
+    SasFrame f = frame_of(c, q, tiles);
     SasOutputs o{};
     o.rgb = a.rgb; o.alpha = a.alpha; o.depth = a.depth; o.rgb8 = a.rgb8;
     o.bg[0] = a.bg[0]; o.bg[1] = a.bg[1]; o.bg[2] = a.bg[2];
 
+    // start after whatever the caller has enqueued on its stream so far
+    HIP_TRY(c, hipEventRecord(sl.start, a.stream));
+    HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, cbytes, st));
+    HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, cbytes, st));
     sas_launch_project(st, c->scene, cam, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
     sas_launch_scan(st, cam, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
     sas_launch_scatter(st, c->scene, cam, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
-    sas_launch_sort(st, c->scene, cam, f, c->stats[SAS_S_MAX_TILE_LEN]);
+    sas_launch_sort(st, c->scene, cam, f, sl.sort_streams);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
     sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0, fill);
@@ -262,14 +274,14 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
     sl.timed = timing;
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, c->counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(sl.done, st));
     sl.busy = true;
-    c->last = a;
+    c->has_frame = true;
     return SAS_OK;
 }
 
-// Verify the oldest in-flight frame; on overflow grow the intersection buffer and render it again.
+// Verify the oldest in-flight frame; on overflow grow its intersection buffer and render it again.
 int complete_oldest(sas_ctx *c)
 {
     if (c->inflight <= 0) return SAS_OK;
@@ -280,7 +292,7 @@ int complete_oldest(sas_ctx *c)
         c->stats[SAS_S_NVISIBLE] = s[0];
         c->stats[SAS_S_NISECT] = s[1];
         c->stats[SAS_S_MAX_TILE_LEN] = s[4];
-        c->stats[SAS_S_CAPACITY] = c->cap;
+        c->stats[SAS_S_CAPACITY] = sl.scr.cap;
         c->stats[SAS_S_REGROWS] = c->regrows;
         c->stats[SAS_S_WINDOW_MISSES] = s[5];
         if (sl.timed) {
@@ -288,15 +300,19 @@ int complete_oldest(sas_ctx *c)
             (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[5]);
         }
         if (!s[2]) {
+            // later work on the caller's stream is ordered after this frame
+            HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
             sl.busy = false;
-            c->head ^= 1;
+            c->head = (c->head + 1) % kSlots;
             c->inflight--;
             return SAS_OK;
         }
-        // intersection buffer too small: drain the stream, grow to the measured need (+25 %), re-render
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // intersection buffer too small: grow to the measured need (+25 %) and render the frame again
         const long long need = (long long)s[1];
-        if (need + need / 4 + 1024 > c->cap) c->cap = need + need / 4 + 1024;
+        const long long want = need + need / 4 + 1024;
+        if (want > sl.scr.cap) sl.scr.cap = want;
+        for (Slot &o : c->slots)   // the other slot will need it too
+            if (o.scr.cap && o.scr.cap < want && !o.busy) o.scr.cap = want;
         c->regrows++;
         int rc = enqueue_frame(c, sl);
         if (rc) return rc;
@@ -332,8 +348,13 @@ int sas_create(int device, sas_ctx **out)
     bool ok = hipSetDevice(device) == hipSuccess;
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
-        ok = ok && hipEventCreate(&sl.done) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&sl.fs, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        for (auto &sd : sl.sort_streams.side) ok = ok && hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.sort_streams.fork, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : sl.sort_streams.join) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (ok) memset(sl.stats_host, 0, 8 * sizeof(unsigned));
     }
     if (!ok) {
@@ -348,16 +369,24 @@ int sas_destroy(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->inflight > 0) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm, &c->rec, &c->info, &c->tilebuf, &c->keys, &c->ids,
-                      &c->counters, &c->wgvis, &c->tilemax})
-        release(*b);
     for (Slot &sl : c->slots) {
+        if (sl.fs) (void)hipStreamSynchronize(sl.fs);
+        for (auto &sd : sl.sort_streams.side)
+            if (sd) { (void)hipStreamSynchronize(sd); (void)hipStreamDestroy(sd); }
+        if (sl.sort_streams.fork) (void)hipEventDestroy(sl.sort_streams.fork);
+        for (auto &e : sl.sort_streams.join)
+            if (e) (void)hipEventDestroy(e);
+        if (sl.fs) (void)hipStreamDestroy(sl.fs);
         if (sl.stats_host) (void)hipHostFree(sl.stats_host);
+        if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
+        for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
+                          &sl.scr.wgvis, &sl.scr.tilemax})
+            release(*b);
     }
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm}) release(*b);
     delete c;
     return SAS_OK;
 }
@@ -463,7 +492,8 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
         HIP_TRY(c, hipMemcpy(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice));
         c->scene.group_Rt = (const float *)c->groups.p;
     }
-    c->cap = 0;  // re-derive the intersection capacity for the new scene
+    for (Slot &sl : c->slots) sl.scr.cap = 0;  // re-derive the intersection capacity for the new scene
+    c->has_frame = false;
     c->has_scene = true;
     return SAS_OK;
 }
@@ -479,7 +509,7 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
         if (rc) return rc;
     }
     c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
-    // stream-ordered behind earlier frames of the same stream; the host copy is ours
+    // no frame is in flight here; later frames start behind the caller's stream, where this copy is queued
     HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice,
                               c->stream));
     return SAS_OK;
@@ -497,15 +527,16 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->inflight > 0 && (st != c->stream || (flags & SAS_TIMING))) {
-        int rc = complete_all(c);   // one stream at a time; timed frames run alone
+        int rc = complete_all(c);   // one caller stream at a time; timed frames run alone
         if (rc) return rc;
     }
-    if (c->inflight == 2) {
+    if (c->inflight == kSlots) {
         int rc = complete_oldest(c);
         if (rc) return rc;
     }
     c->stream = st;
-    Slot &sl = c->slots[(c->head + c->inflight) & 1];
+    const int si = (c->head + c->inflight) % kSlots;
+    Slot &sl = c->slots[si];
     RenderArgs &a = sl.args;
     memcpy(a.viewmat, viewmat, sizeof(a.viewmat));
     memcpy(a.K, K, sizeof(a.K));
@@ -517,6 +548,7 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     int rc = enqueue_frame(c, sl);
     if (rc) return rc;
     c->inflight++;
+    c->last_slot = si;
     if (flags & SAS_ASYNC) return SAS_OK;
     return complete_all(c);
 }
@@ -546,18 +578,19 @@ int sas_frame_stats(sas_ctx *c, int64_t *stats, int n)
 int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depths, float *conics, float *colors)
 {
     if (!c) return SAS_ERR_INVALID;
-    if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
+    if (!c->has_scene || !c->has_frame) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
     HIP_TRY(c, hipSetDevice(c->device));
     {
         int rc = complete_all(c);
         if (rc) return rc;
     }
+    const Scratch &q = c->slots[c->last_slot].scr;
     const int64_t n = c->scene.n;
     std::vector<float> rec((size_t)12 * n);
     std::vector<uint32_t> info((size_t)4 * n);
     if (n > 0) {
-        HIP_TRY(c, hipMemcpy(rec.data(), c->rec.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(info.data(), c->info.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(rec.data(), q.rec.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(info.data(), q.info.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost));
     }
     for (int64_t j = 0; j < n; ++j) {
         const int64_t i = c->perm_host[(size_t)j];   // slot j holds the caller's Gaussian i
@@ -576,20 +609,22 @@ int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depth
 int sas_read_tile_lists(sas_ctx *c, int32_t *tile_offsets, int32_t *sorted_ids, int64_t cap)
 {
     if (!c) return SAS_ERR_INVALID;
-    if (!c->has_scene || !c->last.valid) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
+    if (!c->has_scene || !c->has_frame) return fail(c, SAS_ERR_NO_SCENE, "no frame rendered");
     HIP_TRY(c, hipSetDevice(c->device));
     {
         int rc = complete_all(c);
         if (rc) return rc;
     }
-    const int tiles = c->cam.tw * c->cam.th;
+    const Slot &ls = c->slots[c->last_slot];
+    const Scratch &q = ls.scr;
+    const int tiles = ls.cam.tw * ls.cam.th;
     if (tile_offsets)
-        HIP_TRY(c, hipMemcpy(tile_offsets, c->tilebuf.p, sizeof(int) * (size_t)(tiles + 1), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(tile_offsets, q.tilebuf.p, sizeof(int) * (size_t)(tiles + 1), hipMemcpyDeviceToHost));
     if (sorted_ids) {
         int64_t m = c->stats[SAS_S_NISECT];
         if (m > cap) m = cap;
-        if (m > c->cap) m = c->cap;
-        if (m > 0) HIP_TRY(c, hipMemcpy(sorted_ids, c->ids.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        if (m > q.cap) m = q.cap;
+        if (m > 0) HIP_TRY(c, hipMemcpy(sorted_ids, q.ids.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < m; ++k) {   // storage slots -> caller indices
             const int j = sorted_ids[k];
             sorted_ids[k] = (j >= 0 && j < c->scene.n) ? c->perm_host[(size_t)j] : -1;

@@ -48,6 +48,7 @@ struct SasFrame {
     int *tile_offset;  // [tiles+1]
     int *tile_cursor;  // [tiles]
     int *tile_order;   // [tiles] tiles by descending list length (blend launch order)
+    int *sort_class;   // [4] start of the large / mid / small sort class in tile_order, then tiles
     unsigned long long *keys;  // [cap]  depth bits << 32 | caller index
     int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
@@ -71,7 +72,11 @@ void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *pe
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
 void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
-void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint);
+struct SasSortStreams {
+    hipStream_t side[2];   // nullptr: run the classes back to back on the frame's stream
+    hipEvent_t fork, join[2];
+};
+void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasSortStreams &ss);
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
                       bool fast_exp, bool want_max);
 void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth);

@@ -422,20 +422,38 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, SasCam c, SasFrame 
 }
 
 // ---- k_scan: exclusive scan over tiles (one workgroup) ------------------------------------------
+// Each thread owns 8 consecutive tiles per round and loads them before anything else, so a round
+// costs one memory latency (the counts were written by memory-side atomics and miss every cache).
+// Also: blend launch order (tiles bucketed by floor(log2(length)), longest first, so long lists
+// start early and short ones fill the tail), visible count, max list length, overflow flag.
+constexpr int kScanPer = 8;
+
 __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
 {
     __shared__ int wsum[16];
-    __shared__ int carry_s;
     __shared__ int s_bucket[33];
+    __shared__ int s_bbase[33];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid < 33) s_bucket[tid] = 0;
+    int nvis = 0;
+    for (int i = tid; i < f.n_wg; i += 1024) nvis += f.wg_vis[i];
     __syncthreads();
-    int maxlen = 0;
-    for (int base = 0; base < tiles; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < tiles) ? f.tile_count[i] : 0;
-        maxlen = max(maxlen, v);
-        int incl = v;
+    int carry = 0, maxlen = 0;
+    const int rounds = (tiles + 1024 * kScanPer - 1) / (1024 * kScanPer);
+    // pass 1: offsets + bucket histogram
+    for (int r = 0; r < rounds; ++r) {
+        const int base = (r * 1024 + tid) * kScanPer;
+        int v[kScanPer];
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) v[k] = (base + k < tiles) ? f.tile_count[base + k] : 0;
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            sum += v[k];
+            maxlen = max(maxlen, v[k]);
+            if (base + k < tiles) atomicAdd(&s_bucket[v[k] ? 32 - __clz(v[k]) : 0], 1);
+        }
+        int incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(incl, d);
@@ -443,35 +461,43 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         }
         if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wv; ++k) woff += wsum[k];
-        const int carry = carry_s;
-        const int excl = carry + woff + incl - v;
-        if (i < tiles) { f.tile_offset[i] = excl; f.tile_cursor[i] = excl; }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = wsum[k];
+            if (k < wv) woff += x;
+            total += x;
+        }
+        int run = carry + woff + incl - sum;
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            if (base + k < tiles) { f.tile_offset[base + k] = run; f.tile_cursor[base + k] = run; }
+            run += v[k];
+        }
+        carry += total;
         __syncthreads();
     }
-    // blend launch order: tiles bucketed by floor(log2(length)), longest first, so that the long
-    // lists start early and the short ones fill the tail (order inside a bucket is irrelevant)
-    if (tid < 33) s_bucket[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < tiles; i += 1024) {
-        const int v = f.tile_count[i];
-        atomicAdd(&s_bucket[v ? 32 - __clz(v) : 0], 1);
-    }
-    __syncthreads();
+    // bucket bases, longest lists first
     if (tid == 0) {
         int run = 0;
-        for (int bkt = 32; bkt >= 0; --bkt) { const int cnt = s_bucket[bkt]; s_bucket[bkt] = run; run += cnt; }
+        for (int bkt = 32; bkt >= 0; --bkt) { s_bbase[bkt] = run; run += s_bucket[bkt]; }
+        // bucket b holds lengths [2^(b-1), 2^b): sort classes are bucket ranges, hence contiguous
+        f.sort_class[0] = 0;             // large: length >= 4096 (buckets >= 13)
+        f.sort_class[1] = s_bbase[12];   // mid:   1024..4095     (buckets 11, 12)
+        f.sort_class[2] = s_bbase[10];   // small: < 1024         (buckets <= 10)
+        f.sort_class[3] = tiles;
     }
     __syncthreads();
-    for (int i = tid; i < tiles; i += 1024) {
-        const int v = f.tile_count[i];
-        f.tile_order[atomicAdd(&s_bucket[v ? 32 - __clz(v) : 0], 1)] = i;
+    // pass 2: placement (counts are L2-resident now)
+    for (int r = 0; r < rounds; ++r) {
+        const int base = (r * 1024 + tid) * kScanPer;
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k)
+            if (base + k < tiles) {
+                const int v = f.tile_count[base + k];
+                f.tile_order[atomicAdd(&s_bbase[v ? 32 - __clz(v) : 0], 1)] = base + k;
+            }
     }
-    int nvis = 0;
-    for (int i = tid; i < f.n_wg; i += 1024) nvis += f.wg_vis[i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         maxlen = max(maxlen, __shfl_xor(maxlen, d));
@@ -482,10 +508,9 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         if (nvis) atomicAdd(&f.stats[0], (unsigned)nvis);
     }
     if (tid == 0) {
-        const int total = carry_s;
-        f.tile_offset[tiles] = total;
-        f.stats[1] = (unsigned)total;
-        if ((long long)total > f.cap) f.stats[2] = 1u;
+        f.tile_offset[tiles] = carry;
+        f.stats[1] = (unsigned)carry;
+        if ((long long)carry > f.cap) f.stats[2] = 1u;
     }
 }
 
@@ -546,53 +571,67 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame 
 // key low word = caller index  ->  list entry = storage slot
 DEV int entry_of(const int *inv_perm, unsigned lo) { return inv_perm[lo]; }
 
-template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *inv_perm, int lo_excl)
+DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *inv_perm, int tid, int nthreads);
+
+template <int CAP, int THREADS, bool LAST_CLASS>
+__global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *inv_perm, int cls)
 {
     constexpr int W = THREADS / 64;     // waves
     constexpr int NB = CAP / THREADS;   // 64-key batches per wave
     static_assert(THREADS >= 256 && CAP % THREADS == 0, "radix sort geometry");
-    __shared__ unsigned long long bufA[CAP], bufB[CAP];
+    __shared__ unsigned long long buf[CAP];   // one buffer: between barriers the keys live in registers
     __shared__ unsigned cnt[W][256];
     __shared__ unsigned s_dbase[256];
     __shared__ unsigned s_wsum[4];
     __shared__ unsigned s_or, s_and;
-    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int oi = f.sort_class[cls] + (int)blockIdx.x;
+    if (oi >= f.sort_class[cls + 1]) return;   // not a tile of this class
+    const int t = f.tile_order[oi];
     const long long beg = f.tile_offset[t];
     long long end = f.tile_offset[t + 1];
     if (end > f.cap) end = f.cap;
     const int n = (int)(end - beg);
-    if (n <= lo_excl || n > CAP) return;
-    const unsigned long long *g = f.keys + beg;
+    if (n <= 0 || (!LAST_CLASS && n > CAP)) return;
+    unsigned long long *g = f.keys + beg;
     int *out = f.sorted_ids + beg;
     if (n == 1) {
         if (tid == 0) out[0] = entry_of(inv_perm, (unsigned)g[0]);
         return;
     }
-    if (tid == 0) { s_or = 0u; s_and = ~0u; }
+    if (LAST_CLASS && n > CAP) {   // longer than any LDS class: in place on the global segment
+        sort_global_bitonic(g, out, n, inv_perm, tid, THREADS);
+        return;
+    }
+    if (tid == 0) { s_or = 0u; s_and = ~0u; }   // s_or: max depth word, s_and: min depth word
     __syncthreads();
     // contiguous chunk per wave, balanced over the waves: nbu batches of 64 keys each
     const int nbu = (((n + W - 1) / W) + 63) >> 6;   // <= NB because n <= CAP
     const int base = wv * (nbu * 64) + lane;          // element index of batch b: base + 64 b
     unsigned long long k[NB];
-    unsigned orv = 0u, andv = ~0u;
+    unsigned mn = ~0u, mx = 0u;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int i = base + 64 * b;
         const bool in = b < nbu && i < n;
         k[b] = in ? g[i] : ~0ull;
-        if (in) { orv |= (unsigned)(k[b] >> 32); andv &= (unsigned)(k[b] >> 32); }
+        if (in) { mn = min(mn, (unsigned)(k[b] >> 32)); mx = max(mx, (unsigned)(k[b] >> 32)); }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { orv |= __shfl_xor(orv, d); andv &= __shfl_xor(andv, d); }
-    if (lane == 0) { atomicOr(&s_or, orv); atomicAnd(&s_and, andv); }
+    for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+    if (lane == 0) { atomicMax(&s_or, mx); atomicMin(&s_and, mn); }
     __syncthreads();
-    const unsigned vary = s_or ^ s_and;
-    unsigned long long *src = bufA, *dst = bufB;
+    // sort depth - min(depth): same order, and only the bytes below the range's top bit need a pass
+    const unsigned dmin = s_and;
+    const unsigned vary = s_or - dmin;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < nbu && base + 64 * b < n) k[b] -= (unsigned long long)dmin << 32;
+    unsigned long long *const src = buf, *const dst = buf;
     bool first = true;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int byte = 0; byte < 4; ++byte) {
-        if (((vary >> (8 * byte)) & 0xffu) == 0u) continue;   // uniform
+        if ((vary >> (8 * byte)) == 0u) break;   // uniform
         if (!first) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -652,7 +691,6 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
             }
         }
         __syncthreads();
-        unsigned long long *tmp = src; src = dst; dst = tmp;
         first = false;
     }
     if (first) {   // every depth identical: keys are still only in registers
@@ -680,26 +718,162 @@ __global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *i
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += THREADS) out[i] = entry_of(inv_perm, (unsigned)src[i]);
+    // output: gathers of all of a thread's entries in flight together
+    unsigned lo[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b * THREADS + tid;
+        lo[b] = (i < n) ? (unsigned)entry_of(inv_perm, (unsigned)src[i]) : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b * THREADS + tid;
+        if (i < n) out[i] = (int)lo[b];
+    }
 }
 
-// Lists longer than the largest LDS class: same network in its all-ascending form (the first
-// step of each merge mirrors), virtual +inf padding, in place on the global segment.
-__global__ __launch_bounds__(256) void k_sort_global(SasFrame f, const int *inv_perm, int lo_excl)
+// Lists shorter than 1024: one wave per tile, no workgroup barrier anywhere (a wave executes its
+// LDS operations in order).  The sort runs on (depth word, position in the unsorted segment):
+// 6 bytes of LDS per entry; caller indices are fetched from the L2-hot segment only for depth ties
+// and for the final translation to storage slots.
+__global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *inv_perm, int cls)
 {
-    const int t = blockIdx.x, tid = threadIdx.x;
+    constexpr int CAP = 1024, NB = 16;
+    __shared__ unsigned sd[CAP];
+    __shared__ unsigned short si[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[256];
+    const int lane = threadIdx.x;
+    const int oi = f.sort_class[cls] + (int)blockIdx.x;
+    if (oi >= f.sort_class[cls + 1]) return;
+    const int t = f.tile_order[oi];
     const long long beg = f.tile_offset[t];
     long long end = f.tile_offset[t + 1];
     if (end > f.cap) end = f.cap;
     const int n = (int)(end - beg);
-    if (n <= lo_excl) return;
-    unsigned long long *g = f.keys + beg;
+    if (n <= 0 || n > CAP) return;
+    const unsigned long long *g = f.keys + beg;
     int *out = f.sorted_ids + beg;
+    if (n == 1) {
+        if (lane == 0) out[0] = entry_of(inv_perm, (unsigned)g[0]);
+        return;
+    }
+    const int nb = (n + 63) >> 6;
+    unsigned kd[NB], ki[NB];
+    unsigned mn = ~0u, mx = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = 64 * b + lane;
+        const bool in = b < nb && i < n;
+        kd[b] = in ? (unsigned)(g[i] >> 32) : ~0u;
+        ki[b] = (unsigned)i;
+        if (in) { mn = min(mn, kd[b]); mx = max(mx, kd[b]); }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+    // sort depth - min(depth): same order, and only the bytes below the range's top bit need a pass
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < nb && 64 * b + lane < n) kd[b] -= mn;
+    const unsigned span = mx - mn;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int byte = 0; byte < 4; ++byte) {
+        if ((span >> (8 * byte)) == 0u) break;   // uniform
+        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        unsigned rank[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b >= nb) break;   // uniform
+            const bool act = 64 * b + lane < n;
+            const unsigned d = (kd[b] >> (8 * byte)) & 255u;
+            unsigned long long m = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool on = (d >> bit) & 1u;
+                const unsigned long long bm = __ballot(on);
+                m &= on ? bm : ~bm;
+            }
+            const unsigned below = (unsigned)__popcll(m & lt_mask);
+            const unsigned total = (unsigned)__popcll(m);
+            const unsigned prev = act ? cnt[d] : 0u;
+            if (act && below == 0u) cnt[d] = prev + total;
+            rank[b] = prev + below;
+        }
+        // exclusive scan of the 256 digit counters: 4 per lane + wave scan
+        const uint4 c4 = reinterpret_cast<uint4 *>(cnt)[lane];
+        const unsigned s3 = c4.x + c4.y + c4.z + c4.w;
+        unsigned incl = s3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const unsigned ex = incl - s3;
+        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb && 64 * b + lane < n) {
+                const unsigned pos = cnt[(kd[b] >> (8 * byte)) & 255u] + rank[b];
+                sd[pos] = kd[b];
+                si[pos] = (unsigned short)ki[b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 64 * b + lane;
+            if (b < nb && i < n) { kd[b] = sd[i]; ki[b] = si[i]; }
+        }
+    }
+    // current order back to LDS (also covers "no byte varied")
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = 64 * b + lane;
+        if (b < nb && i < n) { sd[i] = kd[b]; si[i] = (unsigned short)ki[b]; }
+    }
+    // runs of identical depth bits: order by caller index
+    for (int i = lane; i < n; i += 64) {
+        const unsigned hd = sd[i];
+        const bool lead = (i == 0 || sd[i - 1] != hd) && (i + 1 < n) && sd[i + 1] == hd;
+        if (lead) {
+            int j = i + 1;
+            while (j < n && sd[j] == hd) ++j;
+            for (int a = i + 1; a < j; ++a) {
+                const unsigned short va = si[a];
+                const unsigned ka = (unsigned)g[va];
+                int q = a - 1;
+                while (q >= i && (unsigned)g[si[q]] > ka) { si[q + 1] = si[q]; --q; }
+                si[q + 1] = va;
+            }
+        }
+    }
+    // output: all gathers of a phase in flight together (a plain loop would serialise two dependent
+    // L2 round trips per 64 entries, because the stores may alias the tables)
+    unsigned lo[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = 64 * b + lane;
+        lo[b] = (b < nb && i < n) ? (unsigned)g[si[i]] : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = 64 * b + lane;
+        lo[b] = (b < nb && i < n) ? (unsigned)entry_of(inv_perm, lo[b]) : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = 64 * b + lane;
+        if (b < nb && i < n) out[i] = (int)lo[b];
+    }
+}
+
+// Lists longer than the largest LDS class: bitonic network in its all-ascending form (the first
+// step of each merge mirrors), virtual +inf padding, in place on the global segment.
+DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *inv_perm, int tid, int nthreads)
+{
     int P = 2;
     while (P < n) P <<= 1;
     for (int k = 2; k <= P; k <<= 1) {
         const int hk = k >> 1;
-        for (int p = tid; p < (P >> 1); p += 256) {
+        for (int p = tid; p < (P >> 1); p += nthreads) {
             const int blk = (p / hk) * k, o = p % hk;
             const int l = blk + o, r = blk + k - 1 - o;
             if (r < n) {
@@ -709,7 +883,7 @@ __global__ __launch_bounds__(256) void k_sort_global(SasFrame f, const int *inv_
         }
         __syncthreads();
         for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int p = tid; p < (P >> 1); p += 256) {
+            for (int p = tid; p < (P >> 1); p += nthreads) {
                 const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
                 const int r = l | j;
                 if (r < n) {
@@ -720,7 +894,7 @@ __global__ __launch_bounds__(256) void k_sort_global(SasFrame f, const int *inv_
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += 256) out[i] = entry_of(inv_perm, (unsigned)g[i]);
+    for (int i = tid; i < n; i += nthreads) out[i] = entry_of(inv_perm, (unsigned)g[i]);
 }
 
 // ---- k_blend: T6 + T0 epilogue -------------------------------------------------------------------
@@ -971,15 +1145,31 @@ void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, cons
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, c, f);
 }
 
-constexpr int kSortSmall = 2048, kSortLarge = 8192;
+constexpr int kSortMid = 4096, kSortLarge = 16384;
 
-void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, long long max_len_hint)
+// class 0: >= 4096 (LDS up to 16384, longer lists in place), class 1: 1024..4095, class 2: < 1024.
+// The classes are independent and each alone leaves most of the chip idle (few long lists), so
+// they run concurrently: classes 0 and 1 on two side streams forked from / joined to `st`.
+void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasSortStreams &ss)
 {
     const unsigned tiles = (unsigned)(c.tw * c.th);
-    (void)max_len_hint;
-    hipLaunchKernelGGL((k_sort_radix<kSortSmall, 256>), dim3(tiles), dim3(256), 0, st, f, s.inv_perm, 0);
-    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024>), dim3(tiles), dim3(1024), 0, st, f, s.inv_perm, kSortSmall);
-    hipLaunchKernelGGL(k_sort_global, dim3(tiles), dim3(256), 0, st, f, s.inv_perm, kSortLarge);
+    hipStream_t s0 = st, s1 = st;
+    if (ss.side[0]) {
+        (void)hipEventRecord(ss.fork, st);
+        (void)hipStreamWaitEvent(ss.side[0], ss.fork, 0);
+        (void)hipStreamWaitEvent(ss.side[1], ss.fork, 0);
+        s0 = ss.side[0];
+        s1 = ss.side[1];
+    }
+    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(tiles), dim3(1024), 0, s0, f, s.inv_perm, 0);
+    hipLaunchKernelGGL((k_sort_radix<kSortMid, 256, false>), dim3(tiles), dim3(256), 0, s1, f, s.inv_perm, 1);
+    hipLaunchKernelGGL(k_sort_wave, dim3(tiles), dim3(64), 0, st, f, s.inv_perm, 2);
+    if (ss.side[0]) {
+        (void)hipEventRecord(ss.join[0], s0);
+        (void)hipEventRecord(ss.join[1], s1);
+        (void)hipStreamWaitEvent(st, ss.join[0], 0);
+        (void)hipStreamWaitEvent(st, ss.join[1], 0);
+    }
 }
 
 void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,

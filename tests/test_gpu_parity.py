@@ -177,3 +177,36 @@ def test_mid_size_lists_use_the_large_lds_class(rasterizer):
     _upload(rasterizer, sc)
     _compare(rasterizer, sc, cam)
     assert 2048 < rasterizer.stats()["max_tile_len"] <= 8192
+
+
+def test_more_than_8192_tiles(rasterizer):
+    """2100x1300 = 132x82 tiles: the tile scan needs a second round; ragged right/bottom tiles."""
+    sc = make_scene(3000, seed=91, log_scale_mean=float(np.log(0.02)))
+    cam = ring_camera(2100, 1300, 1100.0, yaw_deg=5.0)
+    _upload(rasterizer, sc)
+    _compare(rasterizer, sc, cam)
+
+
+def test_list_longer_than_every_lds_class(rasterizer):
+    """> 16384 splats in one tile: the in-place global fallback of the large sort class."""
+    rng = np.random.default_rng(12)
+    sc = make_scene(20000, seed=95, log_scale_mean=float(np.log(0.003)))
+    sc.means[:] = rng.normal(0, 0.004, size=sc.means.shape).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.01, 0.03)
+    cam = ring_camera(64, 48, 100.0)
+    _upload(rasterizer, sc)
+    _compare(rasterizer, sc, cam)
+    assert rasterizer.stats()["max_tile_len"] > 16384
+
+
+def test_every_sort_class_in_one_frame(rasterizer):
+    """Dense centre falling off outwards: tiles of < 1024, 1024..4095 and >= 4096 entries together."""
+    rng = np.random.default_rng(13)
+    sc = make_scene(60000, seed=96, log_scale_mean=float(np.log(0.004)))
+    sc.means[:] = rng.normal(0, 0.3, size=sc.means.shape).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.01, 0.1)
+    cam = ring_camera(160, 128, 260.0)
+    _upload(rasterizer, sc)
+    _, ref = _compare(rasterizer, sc, cam)
+    lens = np.diff(ref["tile_offsets"])
+    assert (lens >= 4096).any() and ((lens >= 1024) & (lens < 4096)).any() and ((lens > 1) & (lens < 1024)).any()
