@@ -45,13 +45,15 @@ typedef enum {
 #define SAS_ASYNC 2u          /* enqueue only; results valid after sas_wait() */
 #define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
 #define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
+#define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */
 
 /* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
 enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT, SAS_T_BLEND, SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
-       SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */, SAS_S_COUNT };
+       SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
+       SAS_S_FALLBACK_TILES /* tiles the lazy tile kernel handed to the full sort path */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);
@@ -105,7 +107,8 @@ int sas_frame_stats(sas_ctx *ctx, int64_t *stats, int n);
 /* Parity hooks (HOST output pointers, any may be NULL): per-Gaussian projection results and the
  * per-tile sorted lists of the last completed frame, in the layout of gsplat's intermediate
  * tensors (radii [n,2] i32, means2d [n,2], depths [n], conics [n,3], colors [n,3];
- * tile_offsets [tiles+1] i32, sorted_ids [<=cap] i32). */
+ * tile_offsets [tiles+1] i32, sorted_ids [<=cap] i32).  sorted_ids is complete only for a frame
+ * rendered with SAS_FULL_SORT (the default path orders lists lazily, front chunk by front chunk). */
 int sas_read_projection(sas_ctx *ctx, int32_t *radii, float *means2d, float *depths, float *conics,
                         float *colors);
 int sas_read_tile_lists(sas_ctx *ctx, int32_t *tile_offsets, int32_t *sorted_ids, int64_t cap);

@@ -16,8 +16,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libsas_hip.so"
-SOURCES = [CSRC / "sas_kernels.hip", CSRC / "sas_api.cpp"]
-DEPS = SOURCES + [CSRC / "sas_internal.h", PKG.parent / "include" / "sim_a_splat_amd.h"]
+SOURCES = [CSRC / "sas_kernels.hip", CSRC / "sas_tile.hip", CSRC / "sas_api.cpp"]
+DEPS = SOURCES + [CSRC / "sas_internal.h", CSRC / "sas_device.h", PKG.parent / "include" / "sim_a_splat_amd.h"]
 ARCH = "gfx950"
 
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <new>
@@ -57,9 +58,27 @@ struct Slot {
     Scratch scr;
     SasCam cam{};
     bool busy = false, timed = false;
+    // per-frame parameter block (pinned host mirror + device copy) and the captured frame graph
+    SasParams *params_host = nullptr;
+    DevBuf params_dev;
+    hipGraphExec_t gexec = nullptr;
+    struct GraphKey {
+        int W = 0, H = 0;
+        unsigned flags = 0;
+        int64_t n = -1;
+        long long cap = 0;
+        uint64_t scene_version = 0;
+        const void *keys = nullptr, *rec = nullptr, *tilebuf = nullptr, *counters = nullptr;
+        bool operator==(const GraphKey &o) const
+        {
+            return W == o.W && H == o.H && flags == o.flags && n == o.n && cap == o.cap &&
+                   scene_version == o.scene_version && keys == o.keys && rec == o.rec && tilebuf == o.tilebuf &&
+                   counters == o.counters;
+        }
+    } gkey;
 };
 
-constexpr int kSlots = 2;
+constexpr int kMaxSlots = 4;
 
 struct sas_ctx {
     int device = 0;
@@ -71,13 +90,16 @@ struct sas_ctx {
     bool has_scene = false;
     std::vector<float> group_host;
     // frames
-    Slot slots[kSlots];
+    Slot slots[kMaxSlots];
+    int n_slots = 2;     // frames that may be in flight (SAS_SLOTS=1..4 overrides the default of 2)
     int head = 0;        // oldest busy slot
     int inflight = 0;
     int last_slot = 0;   // most recently enqueued (parity hooks)
     hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
     bool has_frame = false;
-    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0};
+    bool use_graphs = true;         // SAS_NO_GRAPH=1 disables frame graphs
+    uint64_t scene_version = 0;
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
@@ -213,6 +235,8 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
     f.tile_cursor = (int *)q.tilebuf.p + (tiles + 1);
     f.tile_order = (int *)q.tilebuf.p + (2 * tiles + 1);
     f.sort_class = (int *)q.tilebuf.p + (3 * tiles + 1);
+    f.fb_range = (int *)q.tilebuf.p + (3 * tiles + 1) + 6;
+    f.fb_tiles = (int *)q.tilebuf.p + (3 * tiles + 1) + 8;
     f.keys = (unsigned long long *)q.keys.p;
     f.sorted_ids = (int *)q.ids.p;
     f.cap = q.cap;
@@ -222,7 +246,42 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
     return f;
 }
 
+// The frame's work on stream `st`: parameter block, counters, the five stages, stats read-back.
+int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
+{
+    const RenderArgs &a = sl.args;
+    const SasCam &cam = sl.cam;
+    const int tiles = cam.tw * cam.th;
+    Scratch &q = sl.scr;
+    size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
+    cbytes = (cbytes + 15) & ~(size_t)15;
+    SasFrame f = frame_of(c, q, tiles);
+    const SasParams *P = (const SasParams *)sl.params_dev.p;
+    HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
+    HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, cbytes, st));
+    sas_launch_project(st, c->scene, P, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
+    sas_launch_scan(st, tiles, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
+    sas_launch_scatter(st, c->scene, cam.tw, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
+    const bool full = (a.flags & SAS_FULL_SORT) != 0;
+    if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
+    const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
+    if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
+    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
+    if (fill) sas_launch_depth_fill(st, tiles, P, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
+    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    return SAS_OK;
+}
+
 // Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
+// Untimed frames replay a hipGraph captured once per (slot, image size, flags, scene, scratch):
+// one launch instead of ~25 runtime calls, which otherwise cost more host time than the frame
+// takes on the GPU.
 int enqueue_frame(sas_ctx *c, Slot &sl)
 {
     const RenderArgs &a = sl.args;
@@ -241,40 +300,62 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     }
     if ((rc = ensure(c, q.rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(3 * tiles + 8)))) return rc;
+    if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(4 * tiles + 16)))) return rc;
     if ((rc = ensure(c, q.counters, cbytes))) return rc;
     if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
     if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
+    if ((rc = ensure(c, sl.params_dev, sizeof(SasParams)))) return rc;
+
+    SasParams &hp = *sl.params_host;
+    hp.cam = cam;
+    hp.out.rgb = a.rgb; hp.out.alpha = a.alpha; hp.out.depth = a.depth; hp.out.rgb8 = a.rgb8;
+    hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
 
     hipStream_t st = sl.fs;
     const bool timing = (a.flags & SAS_TIMING) != 0;
-    SasFrame f = frame_of(c, q, tiles);
-    SasOutputs o{};
-    o.rgb = a.rgb; o.alpha = a.alpha; o.depth = a.depth; o.rgb8 = a.rgb8;
-    o.bg[0] = a.bg[0]; o.bg[1] = a.bg[1]; o.bg[2] = a.bg[2];
-
     // start after whatever the caller has enqueued on its stream so far
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
-    HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, cbytes, st));
-    sas_launch_project(st, c->scene, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
-    sas_launch_scan(st, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
-    sas_launch_scatter(st, c->scene, cam, f);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
-    sas_launch_sort(st, c->scene, cam, f, sl.sort_streams);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
-    const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
-    sas_launch_blend(st, c->scene, cam, f, o, (a.flags & SAS_FAST_EXP) != 0, fill);
-    if (fill) sas_launch_depth_fill(st, cam, f, a.depth);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
+    bool launched = false;
+    if (!timing && c->use_graphs) {
+        Slot::GraphKey key;
+        key.W = a.W; key.H = a.H;
+        key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
+        if (!a.depth) key.flags &= ~SAS_DEPTH_FILL_MAX;
+        key.n = n; key.cap = q.cap; key.scene_version = c->scene_version;
+        key.keys = q.keys.p; key.rec = q.rec.p; key.tilebuf = q.tilebuf.p; key.counters = q.counters.p;
+        if (!sl.gexec || !(key == sl.gkey)) {
+            if (sl.gexec) { (void)hipGraphExecDestroy(sl.gexec); sl.gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int brc = enqueue_body(c, sl, st, false);
+                const hipError_t ee = hipStreamEndCapture(st, &graph);
+                ok = brc == SAS_OK && ee == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&sl.gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {
+                (void)hipGetLastError();
+                sl.gexec = nullptr;
+                c->use_graphs = false;   // capture unsupported here: stay on the eager path
+            } else {
+                sl.gkey = key;
+            }
+        }
+        if (sl.gexec) {
+            HIP_TRY(c, hipGraphLaunch(sl.gexec, st));
+            launched = true;
+        }
+    }
+    if (!launched) {
+        rc = enqueue_body(c, sl, st, timing);
+        if (rc) return rc;
+        HIP_TRY(c, hipGetLastError());
+    }
     sl.timed = timing;
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(sl.done, st));
     sl.busy = true;
     c->has_frame = true;
@@ -295,6 +376,7 @@ int complete_oldest(sas_ctx *c)
         c->stats[SAS_S_CAPACITY] = sl.scr.cap;
         c->stats[SAS_S_REGROWS] = c->regrows;
         c->stats[SAS_S_WINDOW_MISSES] = s[5];
+        c->stats[SAS_S_FALLBACK_TILES] = s[6];
         if (sl.timed) {
             for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
             (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[5]);
@@ -303,7 +385,7 @@ int complete_oldest(sas_ctx *c)
             // later work on the caller's stream is ordered after this frame
             HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
             sl.busy = false;
-            c->head = (c->head + 1) % kSlots;
+            c->head = (c->head + 1) % c->n_slots;
             c->inflight--;
             return SAS_OK;
         }
@@ -346,8 +428,15 @@ int sas_create(int device, sas_ctx **out)
     if (!c) return SAS_ERR_OOM;
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess;
+    if (const char *e = getenv("SAS_NO_GRAPH"))
+        if (atoi(e) != 0) c->use_graphs = false;
+    if (const char *e = getenv("SAS_SLOTS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= kMaxSlots) c->n_slots = v;
+    }
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&sl.params_host, sizeof(SasParams)) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&sl.fs, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
@@ -377,7 +466,10 @@ int sas_destroy(sas_ctx *c)
         for (auto &e : sl.sort_streams.join)
             if (e) (void)hipEventDestroy(e);
         if (sl.fs) (void)hipStreamDestroy(sl.fs);
+        if (sl.gexec) (void)hipGraphExecDestroy(sl.gexec);
         if (sl.stats_host) (void)hipHostFree(sl.stats_host);
+        if (sl.params_host) (void)hipHostFree(sl.params_host);
+        release(sl.params_dev);
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
         for (auto &e : sl.ev)
@@ -494,6 +586,7 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     }
     for (Slot &sl : c->slots) sl.scr.cap = 0;  // re-derive the intersection capacity for the new scene
     c->has_frame = false;
+    c->scene_version++;
     c->has_scene = true;
     return SAS_OK;
 }
@@ -530,12 +623,12 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
         int rc = complete_all(c);   // one caller stream at a time; timed frames run alone
         if (rc) return rc;
     }
-    if (c->inflight == kSlots) {
+    if (c->inflight == c->n_slots) {
         int rc = complete_oldest(c);
         if (rc) return rc;
     }
     c->stream = st;
-    const int si = (c->head + c->inflight) % kSlots;
+    const int si = (c->head + c->inflight) % c->n_slots;
     Slot &sl = c->slots[si];
     RenderArgs &a = sl.args;
     memcpy(a.viewmat, viewmat, sizeof(a.viewmat));

@@ -1,0 +1,76 @@
+// sas_device.h -- device-side helpers shared by sas_kernels.hip and sas_tile.hip.
+// Everything here follows the arithmetic contract of DESIGN.md: IEEE binary32 operations, fused
+// only where fma_() is written (translation units are built with -ffp-contract=off).
+#pragma once
+#include "sas_internal.h"
+
+#pragma clang fp contract(off)
+
+#define DEV __device__ __forceinline__
+
+constexpr float kNear = 0.01f, kFar = 1e10f, kEps2d = 0.3f;
+constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
+
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---- contract transcendental functions (mirror sas_oracle_expf / sas_oracle_logf) -------------
+DEV float c_expf(float x)
+{
+    float t = x * 1.4426950408889634f;
+    t = fmaxf(t, -125.0f);
+    t = fminf(t, 126.0f);
+    float n = __builtin_rintf(t);
+    float f = t - n;
+    float p = 0.0013400432653725147f;
+    p = fma_(p, f, 0.009676037356257439f);
+    p = fma_(p, f, 0.05550327152013779f);
+    p = fma_(p, f, 0.2402210682630539f);
+    p = fma_(p, f, 0.6931471824645996f);
+    p = fma_(p, f, 1.0000001192092896f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+DEV float c_logf(float x)
+{
+    unsigned u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.1111111111f;
+    p = fma_(p, s2, 0.1428571429f);
+    p = fma_(p, s2, 0.2f);
+    p = fma_(p, s2, 0.3333333333f);
+    p = fma_(p, s2, 1.0f);
+    float lnm = (2.0f * s) * p;
+    return fma_((float)e, 0.6931471805599453f, lnm);
+}
+
+DEV float affine3(float r0, float r1, float r2, float t, float v0, float v1, float v2)
+{
+    return fma_(r0, v0, fma_(r1, v1, fma_(r2, v2, t)));
+}
+DEV float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    return fma_(a2, b2, fma_(a1, b1, a0 * b0));
+}
+
+// out = R s R^T, s = xx xy xz yy yz zz
+DEV void rot_sym3(const float *R, const float *s, float *out)
+{
+    const float S[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+    float T[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            T[i][j] = dot3(R[3 * i + 0], R[3 * i + 1], R[3 * i + 2], S[0][j], S[1][j], S[2][j]);
+    out[0] = dot3(T[0][0], T[0][1], T[0][2], R[0], R[1], R[2]);
+    out[1] = dot3(T[0][0], T[0][1], T[0][2], R[3], R[4], R[5]);
+    out[2] = dot3(T[0][0], T[0][1], T[0][2], R[6], R[7], R[8]);
+    out[3] = dot3(T[1][0], T[1][1], T[1][2], R[3], R[4], R[5]);
+    out[4] = dot3(T[1][0], T[1][1], T[1][2], R[6], R[7], R[8]);
+    out[5] = dot3(T[2][0], T[2][1], T[2][2], R[6], R[7], R[8]);
+}
+

@@ -41,6 +41,7 @@ struct SasScene {
 //   info[n]        (x0 | x1<<16, y0 | y1<<16, depth bits, rx | ry<<16): tile rectangle, 0 if culled
 //   stats          [0] n_visible [1] n_isect [2] overflow [3] max ED bits [4] max tile length
 //                  [5] workgroups whose screen window did not fit the LDS histogram (direct atomics)
+//                  [6] tiles handed from the lazy tile kernel to the full sort + blend path
 struct SasFrame {
     float4 *rec;
     uint4 *info;
@@ -48,7 +49,9 @@ struct SasFrame {
     int *tile_offset;  // [tiles+1]
     int *tile_cursor;  // [tiles]
     int *tile_order;   // [tiles] tiles by descending list length (blend launch order)
-    int *sort_class;   // [4] start of the large / mid / small sort class in tile_order, then tiles
+    int *sort_class;   // [6] starts of the large / mid / small sort class in tile_order, tiles; then {0, tiles}
+    int *fb_tiles;     // [tiles] tiles the lazy kernel handed to the full path (count in stats[6])
+    int *fb_range;     // [2] {0, count}
     unsigned long long *keys;  // [cap]  depth bits << 32 | caller index
     int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
@@ -64,19 +67,28 @@ struct SasOutputs {
     float bg[3];
 };
 
+// Per-frame parameters, resident in device memory (one block per frame slot) so that a captured
+// hipGraph of the frame can be replayed with new poses / output buffers without touching its nodes.
+struct SasParams {
+    SasCam cam;
+    SasOutputs out;
+};
+
 // launchers (sas_kernels.hip)
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
                          float4 *col);
-void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
-void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f);
-void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f);
+void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, const SasFrame &f);
+void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f);
+void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f);
 struct SasSortStreams {
     hipStream_t side[2];   // nullptr: run the classes back to back on the frame's stream
     hipEvent_t fork, join[2];
 };
-void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasSortStreams &ss);
-void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
+void sas_launch_sort(hipStream_t st, const SasScene &s, int tiles, const SasFrame &f, const SasSortStreams &ss);
+void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                       bool fast_exp, bool want_max);
-void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth);
+void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+                           bool fast_exp, bool want_max);
+void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f);

@@ -16,79 +16,11 @@
 // sequence of IEEE binary32 operations as oracle/sas_oracle.c -- explicit __builtin_fmaf where
 // the contract fuses, no other contraction (-ffp-contract=off), correctly rounded / and sqrt
 // (hipcc default), polynomial exp/log.  No MFMA: nothing here is a dense contraction.
-#include "sas_internal.h"
+#include "sas_device.h"
 
 #pragma clang fp contract(off)
 
-#define DEV __device__ __forceinline__
-
 namespace {
-
-constexpr float kNear = 0.01f, kFar = 1e10f, kEps2d = 0.3f;
-constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
-
-DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-// ---- contract transcendental functions (mirror sas_oracle_expf / sas_oracle_logf) -------------
-DEV float c_expf(float x)
-{
-    float t = x * 1.4426950408889634f;
-    t = fmaxf(t, -125.0f);
-    t = fminf(t, 126.0f);
-    float n = __builtin_rintf(t);
-    float f = t - n;
-    float p = 0.0013400432653725147f;
-    p = fma_(p, f, 0.009676037356257439f);
-    p = fma_(p, f, 0.05550327152013779f);
-    p = fma_(p, f, 0.2402210682630539f);
-    p = fma_(p, f, 0.6931471824645996f);
-    p = fma_(p, f, 1.0000001192092896f);
-    return __builtin_ldexpf(p, (int)n);
-}
-
-DEV float c_logf(float x)
-{
-    unsigned u = __float_as_uint(x);
-    int e = (int)(u >> 23) - 127;
-    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float s2 = s * s;
-    float p = 0.1111111111f;
-    p = fma_(p, s2, 0.1428571429f);
-    p = fma_(p, s2, 0.2f);
-    p = fma_(p, s2, 0.3333333333f);
-    p = fma_(p, s2, 1.0f);
-    float lnm = (2.0f * s) * p;
-    return fma_((float)e, 0.6931471805599453f, lnm);
-}
-
-DEV float affine3(float r0, float r1, float r2, float t, float v0, float v1, float v2)
-{
-    return fma_(r0, v0, fma_(r1, v1, fma_(r2, v2, t)));
-}
-DEV float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
-{
-    return fma_(a2, b2, fma_(a1, b1, a0 * b0));
-}
-
-// out = R s R^T, s = xx xy xz yy yz zz
-DEV void rot_sym3(const float *R, const float *s, float *out)
-{
-    const float S[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
-    float T[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            T[i][j] = dot3(R[3 * i + 0], R[3 * i + 1], R[3 * i + 2], S[0][j], S[1][j], S[2][j]);
-    out[0] = dot3(T[0][0], T[0][1], T[0][2], R[0], R[1], R[2]);
-    out[1] = dot3(T[0][0], T[0][1], T[0][2], R[3], R[4], R[5]);
-    out[2] = dot3(T[0][0], T[0][1], T[0][2], R[6], R[7], R[8]);
-    out[3] = dot3(T[1][0], T[1][1], T[1][2], R[3], R[4], R[5]);
-    out[4] = dot3(T[1][0], T[1][1], T[1][2], R[6], R[7], R[8]);
-    out[5] = dot3(T[2][0], T[2][1], T[2][2], R[6], R[7], R[8]);
-}
 
 // ---- upload: AoS inputs -> 16-byte planes ------------------------------------------------------
 __global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, const int *perm, const float *means,
@@ -241,8 +173,9 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
 
 // ---- k_project: T1 + T2 + tile counts ----------------------------------------------------------
 template <int DEG>
-__global__ __launch_bounds__(256) void k_project(SasScene s, SasCam c, SasFrame f)
+__global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__restrict__ P, SasFrame f)
 {
+    const SasCam c = P->cam;   // wave-uniform: scalar loads
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < s.n;
     bool vis = false;
@@ -486,6 +419,8 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         f.sort_class[1] = s_bbase[12];   // mid:   1024..4095     (buckets 11, 12)
         f.sort_class[2] = s_bbase[10];   // small: < 1024         (buckets <= 10)
         f.sort_class[3] = tiles;
+        f.sort_class[4] = 0;             // every tile, for the full-path blend
+        f.sort_class[5] = tiles;
     }
     __syncthreads();
     // pass 2: placement (counts are L2-resident now)
@@ -516,20 +451,20 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
 
 // ---- k_scatter: T3 emit ---------------------------------------------------------------------------
 // Same window as k_project: count in LDS, reserve one contiguous run per touched tile with a
-// single returning global atomic, then rank inside the run with LDS atomics.  The key carries the
-// CALLER's Gaussian index (perm[slot]) so that depth ties order exactly as in the reference.
-__global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame f)
+// single returning global atomic, then rank inside the run with LDS atomics.  Key = depth bits << 32
+// | storage slot; the rare runs of identical depth are ordered by the caller's index (perm[slot])
+// when a tile is sorted, exactly as the reference's stable sort orders them.
+__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f)
 {
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
     __shared__ int s_base[kHistBins];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint4 inf = make_uint4(0u, 0u, 0u, 0u);
-    unsigned orig = 0;
-    if (i < s.n) { inf = f.info[i]; orig = (unsigned)s.perm[i]; }
+    if (i < s.n) inf = f.info[i];
     const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
     const bool vis = x1 > x0 && y1 > y0;
-    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)orig;
+    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
@@ -542,7 +477,7 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame 
         __syncthreads();
         for (int b = threadIdx.x; b < w.area; b += 256) {
             const int cnt = s_hist[b];
-            s_base[b] = cnt ? atomicAdd(&f.tile_cursor[(w.Y0 + b / w.ww) * c.tw + w.X0 + b % w.ww], cnt) : 0;
+            s_base[b] = cnt ? atomicAdd(&f.tile_cursor[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww], cnt) : 0;
             s_hist[b] = 0;
         }
         __syncthreads();
@@ -555,555 +490,10 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, SasCam c, SasFrame 
                 }
     }
     const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, c.tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
         const int pos = atomicAdd(&f.tile_cursor[tile], 1);
         if ((long long)pos < f.cap) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
     });
-}
-
-// ---- k_sort: per-tile ascending sort of 64-bit keys ---------------------------------------------
-// Size classes are launched over all tiles; a workgroup whose tile is not in its class exits at
-// once.  The LDS classes run a stable LSD radix sort (8-bit digits) over the depth word only,
-// skipping bytes that do not vary inside the tile, then order the rare runs of identical depth by
-// the caller's Gaussian index: the result equals the reference's stable sort of
-// (tile | depth bits) keys emitted in index order.  Stable ranks come from wave ballots, not LDS
-// atomics.  Sorted caller indices are translated to storage slots (inv_perm) on the way out.
-// key low word = caller index  ->  list entry = storage slot
-DEV int entry_of(const int *inv_perm, unsigned lo) { return inv_perm[lo]; }
-
-DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *inv_perm, int tid, int nthreads);
-
-template <int CAP, int THREADS, bool LAST_CLASS>
-__global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *inv_perm, int cls)
-{
-    constexpr int W = THREADS / 64;     // waves
-    constexpr int NB = CAP / THREADS;   // 64-key batches per wave
-    static_assert(THREADS >= 256 && CAP % THREADS == 0, "radix sort geometry");
-    __shared__ unsigned long long buf[CAP];   // one buffer: between barriers the keys live in registers
-    __shared__ unsigned cnt[W][256];
-    __shared__ unsigned s_dbase[256];
-    __shared__ unsigned s_wsum[4];
-    __shared__ unsigned s_or, s_and;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int oi = f.sort_class[cls] + (int)blockIdx.x;
-    if (oi >= f.sort_class[cls + 1]) return;   // not a tile of this class
-    const int t = f.tile_order[oi];
-    const long long beg = f.tile_offset[t];
-    long long end = f.tile_offset[t + 1];
-    if (end > f.cap) end = f.cap;
-    const int n = (int)(end - beg);
-    if (n <= 0 || (!LAST_CLASS && n > CAP)) return;
-    unsigned long long *g = f.keys + beg;
-    int *out = f.sorted_ids + beg;
-    if (n == 1) {
-        if (tid == 0) out[0] = entry_of(inv_perm, (unsigned)g[0]);
-        return;
-    }
-    if (LAST_CLASS && n > CAP) {   // longer than any LDS class: in place on the global segment
-        sort_global_bitonic(g, out, n, inv_perm, tid, THREADS);
-        return;
-    }
-    if (tid == 0) { s_or = 0u; s_and = ~0u; }   // s_or: max depth word, s_and: min depth word
-    __syncthreads();
-    // contiguous chunk per wave, balanced over the waves: nbu batches of 64 keys each
-    const int nbu = (((n + W - 1) / W) + 63) >> 6;   // <= NB because n <= CAP
-    const int base = wv * (nbu * 64) + lane;          // element index of batch b: base + 64 b
-    unsigned long long k[NB];
-    unsigned mn = ~0u, mx = 0u;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = base + 64 * b;
-        const bool in = b < nbu && i < n;
-        k[b] = in ? g[i] : ~0ull;
-        if (in) { mn = min(mn, (unsigned)(k[b] >> 32)); mx = max(mx, (unsigned)(k[b] >> 32)); }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
-    if (lane == 0) { atomicMax(&s_or, mx); atomicMin(&s_and, mn); }
-    __syncthreads();
-    // sort depth - min(depth): same order, and only the bytes below the range's top bit need a pass
-    const unsigned dmin = s_and;
-    const unsigned vary = s_or - dmin;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b < nbu && base + 64 * b < n) k[b] -= (unsigned long long)dmin << 32;
-    unsigned long long *const src = buf, *const dst = buf;
-    bool first = true;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int byte = 0; byte < 4; ++byte) {
-        if ((vary >> (8 * byte)) == 0u) break;   // uniform
-        if (!first) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int i = base + 64 * b;
-                k[b] = (b < nbu && i < n) ? src[i] : ~0ull;
-            }
-        }
-        for (int d = lane; d < 256; d += 64) cnt[wv][d] = 0u;
-        unsigned rank[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b >= nbu) break;   // uniform
-            const int i = base + 64 * b;
-            const bool act = i < n;
-            const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
-            unsigned long long m = __ballot(act);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const bool on = (d >> bit) & 1u;
-                const unsigned long long bm = __ballot(on);
-                m &= on ? bm : ~bm;
-            }
-            const unsigned below = (unsigned)__popcll(m & lt_mask);
-            const unsigned total = (unsigned)__popcll(m);
-            const unsigned prev = act ? cnt[wv][d] : 0u;
-            if (act && below == 0u) cnt[wv][d] = prev + total;
-            rank[b] = prev + below;
-        }
-        __syncthreads();
-        unsigned tot = 0u, incl = 0u;
-        if (tid < 256) {
-            unsigned run = 0u;
-#pragma unroll
-            for (int w = 0; w < W; ++w) { const unsigned cc = cnt[w][tid]; cnt[w][tid] = run; run += cc; }
-            tot = run;
-            incl = tot;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) s_wsum[wv] = incl;
-        }
-        __syncthreads();
-        if (tid < 256) {
-            unsigned off = incl - tot;
-            for (int w = 0; w < wv; ++w) off += s_wsum[w];
-            s_dbase[tid] = off;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = base + 64 * b;
-            if (b < nbu && i < n) {
-                const unsigned d = ((unsigned)(k[b] >> 32) >> (8 * byte)) & 255u;
-                dst[s_dbase[d] + cnt[wv][d] + rank[b]] = k[b];
-            }
-        }
-        __syncthreads();
-        first = false;
-    }
-    if (first) {   // every depth identical: keys are still only in registers
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = base + 64 * b;
-            if (b < nbu && i < n) src[i] = k[b];
-        }
-        __syncthreads();
-    }
-    // runs of identical depth bits: order by caller index (the run's first element does it;
-    // the depth words other threads look at do not change under the permutation)
-    for (int i = tid; i < n; i += THREADS) {
-        const unsigned hd = (unsigned)(src[i] >> 32);
-        const bool lead = (i == 0 || (unsigned)(src[i - 1] >> 32) != hd) && (i + 1 < n) && (unsigned)(src[i + 1] >> 32) == hd;
-        if (lead) {
-            int j = i + 1;
-            while (j < n && (unsigned)(src[j] >> 32) == hd) ++j;
-            for (int a = i + 1; a < j; ++a) {
-                const unsigned long long v = src[a];
-                int q = a - 1;
-                while (q >= i && src[q] > v) { src[q + 1] = src[q]; --q; }
-                src[q + 1] = v;
-            }
-        }
-    }
-    __syncthreads();
-    // output: gathers of all of a thread's entries in flight together
-    unsigned lo[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = b * THREADS + tid;
-        lo[b] = (i < n) ? (unsigned)entry_of(inv_perm, (unsigned)src[i]) : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = b * THREADS + tid;
-        if (i < n) out[i] = (int)lo[b];
-    }
-}
-
-// Lists shorter than 1024: one wave per tile, no workgroup barrier anywhere (a wave executes its
-// LDS operations in order).  The sort runs on (depth word, position in the unsorted segment):
-// 6 bytes of LDS per entry; caller indices are fetched from the L2-hot segment only for depth ties
-// and for the final translation to storage slots.
-__global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *inv_perm, int cls)
-{
-    constexpr int CAP = 1024, NB = 16;
-    __shared__ unsigned sd[CAP];
-    __shared__ unsigned short si[CAP];
-    __shared__ __attribute__((aligned(16))) unsigned cnt[256];
-    const int lane = threadIdx.x;
-    const int oi = f.sort_class[cls] + (int)blockIdx.x;
-    if (oi >= f.sort_class[cls + 1]) return;
-    const int t = f.tile_order[oi];
-    const long long beg = f.tile_offset[t];
-    long long end = f.tile_offset[t + 1];
-    if (end > f.cap) end = f.cap;
-    const int n = (int)(end - beg);
-    if (n <= 0 || n > CAP) return;
-    const unsigned long long *g = f.keys + beg;
-    int *out = f.sorted_ids + beg;
-    if (n == 1) {
-        if (lane == 0) out[0] = entry_of(inv_perm, (unsigned)g[0]);
-        return;
-    }
-    const int nb = (n + 63) >> 6;
-    unsigned kd[NB], ki[NB];
-    unsigned mn = ~0u, mx = 0u;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = 64 * b + lane;
-        const bool in = b < nb && i < n;
-        kd[b] = in ? (unsigned)(g[i] >> 32) : ~0u;
-        ki[b] = (unsigned)i;
-        if (in) { mn = min(mn, kd[b]); mx = max(mx, kd[b]); }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
-    // sort depth - min(depth): same order, and only the bytes below the range's top bit need a pass
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b < nb && 64 * b + lane < n) kd[b] -= mn;
-    const unsigned span = mx - mn;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int byte = 0; byte < 4; ++byte) {
-        if ((span >> (8 * byte)) == 0u) break;   // uniform
-        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        unsigned rank[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b >= nb) break;   // uniform
-            const bool act = 64 * b + lane < n;
-            const unsigned d = (kd[b] >> (8 * byte)) & 255u;
-            unsigned long long m = __ballot(act);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const bool on = (d >> bit) & 1u;
-                const unsigned long long bm = __ballot(on);
-                m &= on ? bm : ~bm;
-            }
-            const unsigned below = (unsigned)__popcll(m & lt_mask);
-            const unsigned total = (unsigned)__popcll(m);
-            const unsigned prev = act ? cnt[d] : 0u;
-            if (act && below == 0u) cnt[d] = prev + total;
-            rank[b] = prev + below;
-        }
-        // exclusive scan of the 256 digit counters: 4 per lane + wave scan
-        const uint4 c4 = reinterpret_cast<uint4 *>(cnt)[lane];
-        const unsigned s3 = c4.x + c4.y + c4.z + c4.w;
-        unsigned incl = s3;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        const unsigned ex = incl - s3;
-        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b < nb && 64 * b + lane < n) {
-                const unsigned pos = cnt[(kd[b] >> (8 * byte)) & 255u] + rank[b];
-                sd[pos] = kd[b];
-                si[pos] = (unsigned short)ki[b];
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = 64 * b + lane;
-            if (b < nb && i < n) { kd[b] = sd[i]; ki[b] = si[i]; }
-        }
-    }
-    // current order back to LDS (also covers "no byte varied")
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = 64 * b + lane;
-        if (b < nb && i < n) { sd[i] = kd[b]; si[i] = (unsigned short)ki[b]; }
-    }
-    // runs of identical depth bits: order by caller index
-    for (int i = lane; i < n; i += 64) {
-        const unsigned hd = sd[i];
-        const bool lead = (i == 0 || sd[i - 1] != hd) && (i + 1 < n) && sd[i + 1] == hd;
-        if (lead) {
-            int j = i + 1;
-            while (j < n && sd[j] == hd) ++j;
-            for (int a = i + 1; a < j; ++a) {
-                const unsigned short va = si[a];
-                const unsigned ka = (unsigned)g[va];
-                int q = a - 1;
-                while (q >= i && (unsigned)g[si[q]] > ka) { si[q + 1] = si[q]; --q; }
-                si[q + 1] = va;
-            }
-        }
-    }
-    // output: all gathers of a phase in flight together (a plain loop would serialise two dependent
-    // L2 round trips per 64 entries, because the stores may alias the tables)
-    unsigned lo[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = 64 * b + lane;
-        lo[b] = (b < nb && i < n) ? (unsigned)g[si[i]] : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = 64 * b + lane;
-        lo[b] = (b < nb && i < n) ? (unsigned)entry_of(inv_perm, lo[b]) : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = 64 * b + lane;
-        if (b < nb && i < n) out[i] = (int)lo[b];
-    }
-}
-
-// Lists longer than the largest LDS class: bitonic network in its all-ascending form (the first
-// step of each merge mirrors), virtual +inf padding, in place on the global segment.
-DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *inv_perm, int tid, int nthreads)
-{
-    int P = 2;
-    while (P < n) P <<= 1;
-    for (int k = 2; k <= P; k <<= 1) {
-        const int hk = k >> 1;
-        for (int p = tid; p < (P >> 1); p += nthreads) {
-            const int blk = (p / hk) * k, o = p % hk;
-            const int l = blk + o, r = blk + k - 1 - o;
-            if (r < n) {
-                const unsigned long long a = g[l], b = g[r];
-                if (a > b) { g[l] = b; g[r] = a; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int p = tid; p < (P >> 1); p += nthreads) {
-                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int r = l | j;
-                if (r < n) {
-                    const unsigned long long a = g[l], b = g[r];
-                    if (a > b) { g[l] = b; g[r] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < n; i += nthreads) out[i] = entry_of(inv_perm, (unsigned)g[i]);
-}
-
-// ---- k_blend: T6 + T0 epilogue -------------------------------------------------------------------
-// One workgroup (4 waves) per 16x16 tile, launched longest list first.  Wave w owns the 8x8
-// quadrant w, one pixel per lane.  Per batch of 256 list entries every thread stages one 48-byte
-// record in LDS; each wave then ballots the entries whose quadrant mask names it into its own
-// compacted queue and walks only those, front to back.  A wave whose 64 pixels are all
-// terminated stops blending; the workgroup leaves when all four have.
-// Minimum of sigma(dx,dy) = 0.5 (A dx^2 + C dy^2) + B dx dy over a rectangle of pixel centres.
-// A convex quadratic whose centre lies outside the rectangle attains its minimum on an edge.
-DEV float min_sigma_rect(float mx, float my, float A, float B, float C, float nBoverC, float nBoverA,
-                         float xa, float xb, float ya, float yb)
-{
-    const float dxl = mx - xb, dxh = mx - xa, dyl = my - yb, dyh = my - ya;
-    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float dx = e ? dxh : dxl;
-        const float dy = fminf(fmaxf(nBoverC * dx, dyl), dyh);
-        best = fminf(best, 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy);
-        const float ey = e ? dyh : dyl;
-        const float ex = fminf(fmaxf(nBoverA * ey, dxl), dxh);
-        best = fminf(best, 0.5f * (A * ex * ex + C * ey * ey) + B * ex * ey);
-    }
-    return best;
-}
-
-// 4-bit mask of the 8x8 quadrants of tile (tx,ty) that the Gaussian can reach.  Bit q = qx + 2 qy.
-// Computed by the thread that stages the record (one entry per thread, no divergence).
-// A quadrant is dropped only when sigma exceeds the blend stage's skip threshold by a margin
-// (0.05) four orders of magnitude above any rounding difference between this estimate and the
-// contract's per-pixel sigma, so dropping it never changes a pixel.
-DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B, float C, float nBoverC,
-                           float nBoverA, float thr)
-{
-    unsigned m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float xa = (float)(tx * SAS_TILE + (q & 1) * 8) + 0.5f;
-        const float ya = (float)(ty * SAS_TILE + (q >> 1) * 8) + 0.5f;
-        const float ms = min_sigma_rect(mx, my, A, B, C, nBoverC, nBoverA, xa, xa + 7.0f, ya, ya + 7.0f);
-        if (!(ms > thr + 0.05f)) m |= 1u << q;
-    }
-    return m;
-}
-
-struct PixState {
-    float T, r, g, b, d;
-    bool done;
-};
-
-// exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
-// the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
-DEV float c_expf_neg_small(float x)
-{
-    const float t = x * 1.4426950408889634f;
-    const float n = __builtin_rintf(t);
-    const float fr = t - n;
-    float p = 0.0013400432653725147f;
-    p = fma_(p, fr, 0.009676037356257439f);
-    p = fma_(p, fr, 0.05550327152013779f);
-    p = fma_(p, fr, 0.2402210682630539f);
-    p = fma_(p, fr, 0.6931471824645996f);
-    p = fma_(p, fr, 1.0000001192092896f);
-    return __builtin_ldexpf(p, (int)n);
-}
-
-// `cand` = pixel alive, sigma >= 0 and sigma <= thr.  sigma > thr implies alpha < 1/255 with a
-// margin far above rounding, so excluding those lanes takes the same decision as the contract.
-template <bool FAST_EXP>
-DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
-{
-    if (cand) {
-        float E;
-        if (FAST_EXP) E = __expf(-sigma);
-        else E = c_expf_neg_small(-sigma);
-        const float alpha = fminf(kMaxAlpha, op * E);
-        if (!(alpha < kAlphaThr)) {
-            const float nT = p.T * (1.0f - alpha);
-            if (nT <= kTStop) {
-                p.done = true;
-            } else {
-                const float vis = alpha * p.T;
-                p.r = fma_(cr, vis, p.r);
-                p.g = fma_(cg, vis, p.g);
-                p.b = fma_(cb, vis, p.b);
-                p.d = fma_(dep, vis, p.d);
-                p.T = nT;
-            }
-        }
-    }
-}
-
-template <bool FAST_EXP, bool WANT_MAX>
-__global__ __launch_bounds__(256) void k_blend(SasCam c, SasFrame f, SasOutputs o, long long n_gauss)
-{
-    __shared__ float4 q0[256], q1[256], q2[256];
-    __shared__ unsigned s_mask[256];
-    __shared__ unsigned short s_queue[4][256];
-    __shared__ unsigned s_wmax[4];
-    const int tile = f.tile_order[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx = tile % c.tw, ty = tile / c.tw;
-    const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
-    const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
-    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
-    const bool inside = ix < c.W && iy < c.H;
-    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
-    bool wdone = __all(p.done);   // wave-uniform
-
-    const long long beg = f.tile_offset[tile];
-    long long end = f.tile_offset[tile + 1];
-    if (end > f.cap) end = f.cap;
-
-    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
-    unsigned ment = 0u;
-    auto fetch = [&](long long at) {
-        const long long idx = at + tid;
-        ment = 0u;
-        if (idx < end) {
-            long long id = (unsigned)f.sorted_ids[idx];
-            if (id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
-            ra = f.rec[3 * id + 0];
-            rb = f.rec[3 * id + 1];
-            rc = f.rec[3 * id + 2];
-            // approximate reciprocals are fine: the mask is conservative by a 0.05 margin in sigma
-            ment = quadrant_mask(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, -ra.w * __builtin_amdgcn_rcpf(rb.x),
-                                 -ra.w * __builtin_amdgcn_rcpf(ra.z), rb.z);
-        }
-    };
-    if (beg < end) fetch(beg);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (long long at = beg; at < end; at += 256) {
-        // the previous batch is fully consumed; leave once every wave has terminated
-        if (__syncthreads_and(wdone)) break;
-        q0[tid] = ra; q1[tid] = rb; q2[tid] = rc; s_mask[tid] = ment;
-        __syncthreads();
-        if (at + 256 < end) fetch(at + 256);   // next batch in flight while this one is blended
-        if (!wdone) {
-            const int cnt = (int)((end - at) < 256 ? (end - at) : 256);
-            int qn = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = j * 64 + lane;
-                const bool has = e < cnt && ((s_mask[e] >> wv) & 1u);
-                const unsigned long long m = __ballot(has);
-                if (has) s_queue[wv][qn + (int)__popcll(m & lt_mask)] = (unsigned short)e;
-                qn += (int)__popcll(m);
-            }
-            for (int k = 0; k < qn; ++k) {
-                const int e = s_queue[wv][k];
-                const float4 A = q0[e], B = q1[e], C = q2[e];
-                const float dx = A.x - px, dy = A.y - py;
-                const float sg = fma_(0.5f, fma_(B.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
-                const bool cand = !p.done && sg >= 0.0f && sg <= B.z;
-                if (__any(cand)) {
-                    blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
-                    if (__all(p.done)) break;
-                }
-            }
-            wdone = __all(p.done);
-        }
-    }
-
-    float ED = 0.0f;
-    if (inside) {
-        const float a = 1.0f - p.T;
-        ED = p.d / fmaxf(a, 1e-10f);
-        const long long pix = (long long)iy * c.W + ix;
-        const float w = 1.0f - a;
-        float v0 = p.r + w * o.bg[0], v1 = p.g + w * o.bg[1], v2 = p.b + w * o.bg[2];
-        v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
-        v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
-        v2 = fminf(fmaxf(v2, 0.0f), 1.0f);
-        if (o.rgb) { o.rgb[3 * pix] = v0; o.rgb[3 * pix + 1] = v1; o.rgb[3 * pix + 2] = v2; }
-        if (o.alpha) o.alpha[pix] = a;
-        if (o.depth) o.depth[pix] = ED;
-        if (o.rgb8) {
-            o.rgb8[3 * pix] = (uint8_t)(int)floorf(fma_(v0, 255.0f, 0.5f));
-            o.rgb8[3 * pix + 1] = (uint8_t)(int)floorf(fma_(v1, 255.0f, 0.5f));
-            o.rgb8[3 * pix + 2] = (uint8_t)(int)floorf(fma_(v2, 255.0f, 0.5f));
-        }
-    }
-    if (WANT_MAX) {   // uniform
-        float maxed = ED;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
-        if (lane == 0) s_wmax[wv] = __float_as_uint(maxed);
-        __syncthreads();
-        if (tid == 0) f.tile_max[tile] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));   // reduced by k_depth_fill
-    }
-}
-
-// depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
-// Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
-// no same-address atomics.  ED >= 0, so the float order is the order of the bit patterns.
-__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *tile_max, int tiles, float *depth, long long npix)
-{
-    __shared__ unsigned s_max[4];
-    unsigned m = 0;
-    for (int t = threadIdx.x; t < tiles; t += 256) m = max(m, tile_max[t]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
-    __syncthreads();
-    const float mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
-        if (depth[p] == 0.0f) depth[p] = mx;
 }
 
 }  // namespace
@@ -1120,76 +510,28 @@ void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *pe
                        coeff_floats, planes, gid, g0, g1, g2, col);
 }
 
-void sas_launch_project(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f)
+void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, const SasFrame &f)
 {
     if (s.n <= 0) return;
     const unsigned grid = (unsigned)((s.n + 255) / 256);
     switch (s.sh_degree) {
-        case 0: hipLaunchKernelGGL(k_project<0>, dim3(grid), dim3(256), 0, st, s, c, f); break;
-        case 1: hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, st, s, c, f); break;
-        case 2: hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, st, s, c, f); break;
-        case 3: hipLaunchKernelGGL(k_project<3>, dim3(grid), dim3(256), 0, st, s, c, f); break;
-        default: hipLaunchKernelGGL(k_project<-1>, dim3(grid), dim3(256), 0, st, s, c, f); break;
+        case 0: hipLaunchKernelGGL(k_project<0>, dim3(grid), dim3(256), 0, st, s, P, f); break;
+        case 1: hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, st, s, P, f); break;
+        case 2: hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, st, s, P, f); break;
+        case 3: hipLaunchKernelGGL(k_project<3>, dim3(grid), dim3(256), 0, st, s, P, f); break;
+        default: hipLaunchKernelGGL(k_project<-1>, dim3(grid), dim3(256), 0, st, s, P, f); break;
     }
 }
 
-void sas_launch_scan(hipStream_t st, const SasCam &c, const SasFrame &f)
+void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, f, c.tw * c.th);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, f, tiles);
 }
 
-void sas_launch_scatter(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f)
+void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f)
 {
     if (s.n <= 0) return;
     const unsigned grid = (unsigned)((s.n + 255) / 256);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, c, f);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, tw, f);
 }
 
-constexpr int kSortMid = 4096, kSortLarge = 16384;
-
-// class 0: >= 4096 (LDS up to 16384, longer lists in place), class 1: 1024..4095, class 2: < 1024.
-// The classes are independent and each alone leaves most of the chip idle (few long lists), so
-// they run concurrently: classes 0 and 1 on two side streams forked from / joined to `st`.
-void sas_launch_sort(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasSortStreams &ss)
-{
-    const unsigned tiles = (unsigned)(c.tw * c.th);
-    hipStream_t s0 = st, s1 = st;
-    if (ss.side[0]) {
-        (void)hipEventRecord(ss.fork, st);
-        (void)hipStreamWaitEvent(ss.side[0], ss.fork, 0);
-        (void)hipStreamWaitEvent(ss.side[1], ss.fork, 0);
-        s0 = ss.side[0];
-        s1 = ss.side[1];
-    }
-    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(tiles), dim3(1024), 0, s0, f, s.inv_perm, 0);
-    hipLaunchKernelGGL((k_sort_radix<kSortMid, 256, false>), dim3(tiles), dim3(256), 0, s1, f, s.inv_perm, 1);
-    hipLaunchKernelGGL(k_sort_wave, dim3(tiles), dim3(64), 0, st, f, s.inv_perm, 2);
-    if (ss.side[0]) {
-        (void)hipEventRecord(ss.join[0], s0);
-        (void)hipEventRecord(ss.join[1], s1);
-        (void)hipStreamWaitEvent(st, ss.join[0], 0);
-        (void)hipStreamWaitEvent(st, ss.join[1], 0);
-    }
-}
-
-void sas_launch_blend(hipStream_t st, const SasScene &s, const SasCam &c, const SasFrame &f, const SasOutputs &o,
-                      bool fast_exp, bool want_max)
-{
-    const unsigned grid = (unsigned)(c.tw * c.th);
-    const long long n = s.n > 0 ? s.n : 1;
-    if (fast_exp) {
-        if (want_max) hipLaunchKernelGGL((k_blend<true, true>), dim3(grid), dim3(256), 0, st, c, f, o, n);
-        else hipLaunchKernelGGL((k_blend<true, false>), dim3(grid), dim3(256), 0, st, c, f, o, n);
-    } else {
-        if (want_max) hipLaunchKernelGGL((k_blend<false, true>), dim3(grid), dim3(256), 0, st, c, f, o, n);
-        else hipLaunchKernelGGL((k_blend<false, false>), dim3(grid), dim3(256), 0, st, c, f, o, n);
-    }
-}
-
-void sas_launch_depth_fill(hipStream_t st, const SasCam &c, const SasFrame &f, float *depth)
-{
-    const long long npix = (long long)c.W * c.H;
-    unsigned grid = (unsigned)((npix + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_depth_fill, dim3(grid), dim3(256), 0, st, (const unsigned *)f.tile_max, c.tw * c.th, depth, npix);
-}

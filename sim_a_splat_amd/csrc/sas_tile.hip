@@ -1,0 +1,881 @@
+// sas_tile.hip -- per-tile work: depth ordering (T4/T5) and front-to-back compositing (T6 + T0).
+//
+// Production path: k_tile_lazy.  Compositing stops once every pixel of a tile is opaque, which in
+// practice happens a fraction of the way into the tile's list, so ordering the whole list (what a
+// global radix sort does) is mostly wasted work.  One workgroup per 16x16 tile (longest list
+// first) buckets the tile's UNSORTED keys by depth (256 buckets over the tile's own depth range),
+// pulls the nearest <= 1024 entries into LDS, radix-sorts only that chunk, composites it, and
+// fetches the next buckets only while some pixel is still alive.
+//
+// Full path (k_sort_* + k_blend): orders every list completely and writes the per-tile lists to
+// memory, exactly the T4/T5 products of the reference (read back by sas_read_tile_lists for the
+// parity tests).  It is also the fallback for the rare tile the lazy kernel gives up on (more
+// than 1024 entries inside one depth bucket, e.g. thousands of coplanar splats).
+//
+// Both paths composite through the same code (blend_range) and therefore produce identical bits.
+#include "sas_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+DEV unsigned hi32(unsigned long long k) { return (unsigned)(k >> 32); }
+DEV unsigned *s_queue_u32(unsigned char *raw) { return reinterpret_cast<unsigned *>(raw); }   // scratch words in a free LDS region
+DEV unsigned lo32(unsigned long long k) { return (unsigned)k; }
+
+// order of the reference: depth bits, then the CALLER's Gaussian index.  Keys carry the storage
+// slot in the low word; perm[slot] is looked up only when two depth words are identical.
+DEV bool key_greater(unsigned long long a, unsigned long long b, const int *perm)
+{
+    const unsigned ha = hi32(a), hb = hi32(b);
+    if (ha != hb) return ha > hb;
+    return perm[lo32(a)] > perm[lo32(b)];
+}
+
+// ================================================================================================
+// LDS radix sort building blocks
+// ================================================================================================
+
+// Stable LSD radix sort (8-bit digits) of m 64-bit keys in LDS by their HIGH word, for a workgroup
+// of W waves.  Only the bytes below the top set bit of `span` (largest high word) get a pass.
+// Ranks come from wave ballots, so equal digits keep their order (a returning LDS atomic would
+// not).  Between barriers the keys live in registers, which makes one buffer enough.
+// Afterwards runs of identical high words are ordered by perm[low word].
+template <int W, int NB>
+DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int *perm, unsigned *cnt /*[W][256]*/,
+                        unsigned *dbase /*[256]*/, unsigned *wsum /*[4]*/)
+{
+    constexpr int THREADS = W * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nbu = (((m + W - 1) / W) + 63) >> 6;   // 64-key batches per wave, <= NB
+    const int base = wv * (nbu * 64) + lane;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long k[NB];
+    for (int byte = 0; byte < 4; ++byte) {
+        if ((span >> (8 * byte)) == 0u) break;   // uniform
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = base + 64 * b;
+            k[b] = (b < nbu && i < m) ? buf[i] : ~0ull;
+        }
+        for (int d = lane; d < 256; d += 64) cnt[wv * 256 + d] = 0u;
+        unsigned rank[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b >= nbu) break;   // uniform
+            const bool act = base + 64 * b < m;
+            const unsigned d = (hi32(k[b]) >> (8 * byte)) & 255u;
+            unsigned long long mm = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool on = (d >> bit) & 1u;
+                const unsigned long long bm = __ballot(on);
+                mm &= on ? bm : ~bm;
+            }
+            const unsigned below = (unsigned)__popcll(mm & lt_mask);
+            const unsigned total = (unsigned)__popcll(mm);
+            const unsigned prev = act ? cnt[wv * 256 + d] : 0u;
+            if (act && below == 0u) cnt[wv * 256 + d] = prev + total;
+            rank[b] = prev + below;
+        }
+        __syncthreads();
+        unsigned tot = 0u, incl = 0u;
+        if (tid < 256) {
+            unsigned run = 0u;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { const unsigned cc = cnt[w * 256 + tid]; cnt[w * 256 + tid] = run; run += cc; }
+            tot = run;
+            incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) wsum[wv] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned off = incl - tot;
+            for (int w = 0; w < wv; ++w) off += wsum[w];
+            dbase[tid] = off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = base + 64 * b;
+            if (b < nbu && i < m) {
+                const unsigned d = (hi32(k[b]) >> (8 * byte)) & 255u;
+                buf[dbase[d] + cnt[wv * 256 + d] + rank[b]] = k[b];
+            }
+        }
+        __syncthreads();
+    }
+    // runs of identical depth: order by caller index (the run's first element does it; the high
+    // words other threads compare do not change under the permutation)
+    for (int i = tid; i < m; i += THREADS) {
+        const unsigned hd = hi32(buf[i]);
+        const bool lead = (i == 0 || hi32(buf[i - 1]) != hd) && (i + 1 < m) && hi32(buf[i + 1]) == hd;
+        if (lead) {
+            int j = i + 1;
+            while (j < m && hi32(buf[j]) == hd) ++j;
+            for (int a = i + 1; a < j; ++a) {
+                const unsigned long long v = buf[a];
+                const int pv = perm[lo32(v)];
+                int q = a - 1;
+                while (q >= i && perm[lo32(buf[q])] > pv) { buf[q + 1] = buf[q]; --q; }
+                buf[q + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Lists longer than every LDS class: bitonic network in its all-ascending form (the first step
+// of each merge mirrors), virtual +inf padding, in place on the global segment.
+DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *perm, int tid, int nthreads)
+{
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = tid; p < (P >> 1); p += nthreads) {
+            const int blk = (p / hk) * k, o = p % hk;
+            const int l = blk + o, r = blk + k - 1 - o;
+            if (r < n) {
+                const unsigned long long a = g[l], b = g[r];
+                if (key_greater(a, b, perm)) { g[l] = b; g[r] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int p = tid; p < (P >> 1); p += nthreads) {
+                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int r = l | j;
+                if (r < n) {
+                    const unsigned long long a = g[l], b = g[r];
+                    if (key_greater(a, b, perm)) { g[l] = b; g[r] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += nthreads) out[i] = (int)lo32(g[i]);
+}
+
+// ================================================================================================
+// Full path, stage 1: k_sort_* write every tile's complete front-to-back list (storage slots)
+// ================================================================================================
+// Tiles come from a list (`tl[range[0] .. range[1])`): the three size classes are contiguous
+// ranges of the length-ordered tile list built by k_scan, and the lazy kernel's fallback tiles are
+// a list of their own.  Workgroups stride over the range.
+
+template <int CAP, int THREADS, bool LAST_CLASS>
+__global__ __launch_bounds__(THREADS) void k_sort_radix(SasFrame f, const int *perm, const int *tl, const int *range)
+{
+    constexpr int W = THREADS / 64, NB = CAP / THREADS;
+    __shared__ unsigned long long buf[CAP];
+    __shared__ unsigned cnt[W * 256];
+    __shared__ unsigned s_dbase[256];
+    __shared__ unsigned s_wsum[4];
+    __shared__ unsigned s_mx, s_mn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
+        const int t = tl[oi];
+        const long long beg = f.tile_offset[t];
+        long long end = f.tile_offset[t + 1];
+        if (end > f.cap) end = f.cap;
+        const int n = (int)(end - beg);
+        if (n <= 0 || (!LAST_CLASS && n > CAP)) continue;
+        unsigned long long *g = f.keys + beg;
+        int *out = f.sorted_ids + beg;
+        if (n == 1) {
+            if (tid == 0) out[0] = (int)lo32(g[0]);
+            continue;
+        }
+        if (LAST_CLASS && n > CAP) {
+            sort_global_bitonic(g, out, n, perm, tid, THREADS);
+            continue;
+        }
+        if (tid == 0) { s_mx = 0u; s_mn = ~0u; }
+        __syncthreads();
+        unsigned mn = ~0u, mx = 0u;
+        for (int i = tid; i < n; i += THREADS) {
+            const unsigned long long key = g[i];
+            buf[i] = key;
+            mn = min(mn, hi32(key));
+            mx = max(mx, hi32(key));
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+        if (lane == 0) { atomicMax(&s_mx, mx); atomicMin(&s_mn, mn); }
+        __syncthreads();
+        // sort depth - min(depth): same order, fewer significant bytes
+        const unsigned dmin = s_mn, span = s_mx - s_mn;
+        for (int i = tid; i < n; i += THREADS) buf[i] -= (unsigned long long)dmin << 32;
+        __syncthreads();
+        lds_radix_sort<W, NB>(buf, n, span, perm, cnt, s_dbase, s_wsum);
+        for (int i = tid; i < n; i += THREADS) out[i] = (int)lo32(buf[i]);
+        __syncthreads();
+    }
+}
+
+// Lists shorter than 1024: one wave per tile, no workgroup barrier anywhere (a wave executes its
+// LDS operations in order).  Sorts (depth word, position in the unsorted segment): 6 bytes of LDS
+// per entry.
+__global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *perm, const int *tl, const int *range)
+{
+    constexpr int CAP = 1024, NB = 16;
+    __shared__ unsigned sd[CAP];
+    __shared__ unsigned short si[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[256];
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
+        const int t = tl[oi];
+        const long long beg = f.tile_offset[t];
+        long long end = f.tile_offset[t + 1];
+        if (end > f.cap) end = f.cap;
+        const int n = (int)(end - beg);
+        if (n <= 0 || n > CAP) continue;
+        const unsigned long long *g = f.keys + beg;
+        int *out = f.sorted_ids + beg;
+        if (n == 1) {
+            if (lane == 0) out[0] = (int)lo32(g[0]);
+            continue;
+        }
+        const int nb = (n + 63) >> 6;
+        unsigned kd[NB], ki[NB];
+        unsigned mn = ~0u, mx = 0u;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 64 * b + lane;
+            const bool in = b < nb && i < n;
+            kd[b] = in ? hi32(g[i]) : ~0u;
+            ki[b] = (unsigned)i;
+            if (in) { mn = min(mn, kd[b]); mx = max(mx, kd[b]); }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < nb && 64 * b + lane < n) kd[b] -= mn;
+        const unsigned span = mx - mn;
+        for (int byte = 0; byte < 4; ++byte) {
+            if ((span >> (8 * byte)) == 0u) break;   // uniform
+            reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            unsigned rank[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b >= nb) break;   // uniform
+                const bool act = 64 * b + lane < n;
+                const unsigned d = (kd[b] >> (8 * byte)) & 255u;
+                unsigned long long m = __ballot(act);
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const bool on = (d >> bit) & 1u;
+                    const unsigned long long bm = __ballot(on);
+                    m &= on ? bm : ~bm;
+                }
+                const unsigned below = (unsigned)__popcll(m & lt_mask);
+                const unsigned total = (unsigned)__popcll(m);
+                const unsigned prev = act ? cnt[d] : 0u;
+                if (act && below == 0u) cnt[d] = prev + total;
+                rank[b] = prev + below;
+            }
+            const uint4 c4 = reinterpret_cast<uint4 *>(cnt)[lane];
+            const unsigned s3 = c4.x + c4.y + c4.z + c4.w;
+            unsigned incl = s3;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const unsigned ex = incl - s3;
+            reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < nb && 64 * b + lane < n) {
+                    const unsigned pos = cnt[(kd[b] >> (8 * byte)) & 255u] + rank[b];
+                    sd[pos] = kd[b];
+                    si[pos] = (unsigned short)ki[b];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = 64 * b + lane;
+                if (b < nb && i < n) { kd[b] = sd[i]; ki[b] = si[i]; }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 64 * b + lane;
+            if (b < nb && i < n) { sd[i] = kd[b]; si[i] = (unsigned short)ki[b]; }
+        }
+        for (int i = lane; i < n; i += 64) {
+            const unsigned hd = sd[i];
+            const bool lead = (i == 0 || sd[i - 1] != hd) && (i + 1 < n) && sd[i + 1] == hd;
+            if (lead) {
+                int j = i + 1;
+                while (j < n && sd[j] == hd) ++j;
+                for (int a = i + 1; a < j; ++a) {
+                    const unsigned short va = si[a];
+                    const int pa = perm[lo32(g[va])];
+                    int q = a - 1;
+                    while (q >= i && perm[lo32(g[si[q]])] > pa) { si[q + 1] = si[q]; --q; }
+                    si[q + 1] = va;
+                }
+            }
+        }
+        unsigned lo[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 64 * b + lane;
+            lo[b] = (b < nb && i < n) ? lo32(g[si[i]]) : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 64 * b + lane;
+            if (b < nb && i < n) out[i] = (int)lo[b];
+        }
+    }
+}
+
+// ================================================================================================
+// Compositing
+// ================================================================================================
+
+// Minimum of sigma(dx,dy) = 0.5 (A dx^2 + C dy^2) + B dx dy over a rectangle of pixel centres.
+// A convex quadratic whose centre lies outside the rectangle attains its minimum on an edge.
+DEV float min_sigma_rect(float mx, float my, float A, float B, float C, float nBoverC, float nBoverA,
+                         float xa, float xb, float ya, float yb)
+{
+    const float dxl = mx - xb, dxh = mx - xa, dyl = my - yb, dyh = my - ya;
+    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e ? dxh : dxl;
+        const float dy = fminf(fmaxf(nBoverC * dx, dyl), dyh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy);
+        const float ey = e ? dyh : dyl;
+        const float ex = fminf(fmaxf(nBoverA * ey, dxl), dxh);
+        best = fminf(best, 0.5f * (A * ex * ex + C * ey * ey) + B * ex * ey);
+    }
+    return best;
+}
+
+// 4-bit mask of the 8x8 quadrants of tile (tx,ty) that the Gaussian can reach.  Bit q = qx + 2 qy.
+// Computed by the thread that stages the record (one entry per thread, no divergence).
+// A quadrant is dropped only when sigma exceeds the blend loop's skip threshold by a margin
+// (0.05) four orders of magnitude above any rounding difference between this estimate and the
+// contract's per-pixel sigma, so dropping it never changes a pixel.
+DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B, float C, float thr)
+{
+    // approximate reciprocals are fine: conservative by the margin
+    const float nBoverC = -B * __builtin_amdgcn_rcpf(C), nBoverA = -B * __builtin_amdgcn_rcpf(A);
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xa = (float)(tx * SAS_TILE + (q & 1) * 8) + 0.5f;
+        const float ya = (float)(ty * SAS_TILE + (q >> 1) * 8) + 0.5f;
+        const float ms = min_sigma_rect(mx, my, A, B, C, nBoverC, nBoverA, xa, xa + 7.0f, ya, ya + 7.0f);
+        if (!(ms > thr + 0.05f)) m |= 1u << q;
+    }
+    return m;
+}
+
+struct PixState {
+    float T, r, g, b, d;
+    bool done;
+};
+
+// exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
+// the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
+DEV float c_expf_neg_small(float x)
+{
+    const float t = x * 1.4426950408889634f;
+    const float n = __builtin_rintf(t);
+    const float fr = t - n;
+    float p = 0.0013400432653725147f;
+    p = fma_(p, fr, 0.009676037356257439f);
+    p = fma_(p, fr, 0.05550327152013779f);
+    p = fma_(p, fr, 0.2402210682630539f);
+    p = fma_(p, fr, 0.6931471824645996f);
+    p = fma_(p, fr, 1.0000001192092896f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+// `cand` = pixel alive, sigma >= 0 and sigma <= thr.  sigma > thr implies alpha < 1/255 with a
+// margin far above rounding, so excluding those lanes takes the same decision as the contract.
+template <bool FAST_EXP>
+DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
+{
+    if (cand) {
+        float E;
+        if (FAST_EXP) E = __expf(-sigma);
+        else E = c_expf_neg_small(-sigma);
+        const float alpha = fminf(kMaxAlpha, op * E);
+        if (!(alpha < kAlphaThr)) {
+            const float nT = p.T * (1.0f - alpha);
+            if (nT <= kTStop) {
+                p.done = true;
+            } else {
+                const float vis = alpha * p.T;
+                p.r = fma_(cr, vis, p.r);
+                p.g = fma_(cg, vis, p.g);
+                p.b = fma_(cb, vis, p.b);
+                p.d = fma_(dep, vis, p.d);
+                p.T = nT;
+            }
+        }
+    }
+}
+
+// LDS of the compositing loop: one staged batch of 256 records + per-wave compacted queues.
+struct BlendLds {
+    float4 *q0, *q1, *q2;       // [256] each
+    unsigned *mask;             // [256]
+    unsigned short *queue;      // [4][256]
+};
+constexpr int kBlendLdsBytes = 3 * 256 * 16 + 256 * 4 + 4 * 256 * 2;   // 15360
+
+// Composite entries [0, count) of a depth-ordered list onto this thread's pixel.  Wave w owns the
+// 8x8 quadrant w of the tile, one pixel per lane.  Per batch of 256 entries every thread stages
+// one 48-byte record with its quadrant mask; each wave ballots the entries that name its quadrant
+// into its own queue and walks only those, front to back.  Returns true when every pixel of the
+// tile has terminated (uniform over the workgroup).  `slot_at(i)` gives the storage slot of
+// entry i.
+template <bool FAST_EXP, typename SlotAt>
+DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float px, float py, int count, SlotAt slot_at,
+                     const BlendLds &L, PixState &p, bool &wdone)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+    bool have = false;
+    // only issues the loads: nothing here may depend on their results
+    auto fetch = [&](int at) {
+        const int idx = at + tid;
+        have = idx < count;
+        if (have) {
+            long long id = slot_at(idx);
+            if (id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
+            ra = f.rec[3 * id + 0];
+            rb = f.rec[3 * id + 1];
+            rc = f.rec[3 * id + 2];
+        }
+    };
+    if (count > 0) fetch(0);
+    bool all_done = false;
+    for (int at = 0; at < count; at += 256) {
+        // the previous batch is fully consumed; leave once every wave has terminated
+        if (__syncthreads_and(wdone)) { all_done = true; break; }
+        unsigned ment = 0u;
+        if (have) ment = quadrant_mask(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+        L.q0[tid] = ra; L.q1[tid] = rb; L.q2[tid] = rc; L.mask[tid] = ment;
+        __syncthreads();
+        if (at + 256 < count) fetch(at + 256);   // next batch in flight while this one is blended
+        if (!wdone) {
+            const int cnt = (count - at) < 256 ? (count - at) : 256;
+            unsigned short *queue = L.queue + wv * 256;
+            int qn = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = j * 64 + lane;
+                const bool has = e < cnt && ((L.mask[e] >> wv) & 1u);
+                const unsigned long long m = __ballot(has);
+                if (has) queue[qn + (int)__popcll(m & lt_mask)] = (unsigned short)e;
+                qn += (int)__popcll(m);
+            }
+            for (int k = 0; k < qn; ++k) {
+                const int e = queue[k];
+                const float4 A = L.q0[e], B = L.q1[e], C = L.q2[e];
+                const float dx = A.x - px, dy = A.y - py;
+                const float sg = fma_(0.5f, fma_(B.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
+                const bool cand = !p.done && sg >= 0.0f && sg <= B.z;
+                if (__any(cand)) {
+                    blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
+                    if (__all(p.done)) break;
+                }
+            }
+            wdone = __all(p.done);
+        }
+    }
+    if (!all_done) all_done = __syncthreads_and(wdone);   // also fences the staging buffers
+    return all_done;
+}
+
+// T0 epilogue for this thread's pixel; returns its expected depth (0 outside the image).
+DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W)
+{
+    if (!inside) return 0.0f;
+    const float a = 1.0f - p.T;
+    const float ED = p.d / fmaxf(a, 1e-10f);
+    const long long pix = (long long)iy * W + ix;
+    const float w = 1.0f - a;
+    float v0 = p.r + w * o.bg[0], v1 = p.g + w * o.bg[1], v2 = p.b + w * o.bg[2];
+    v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
+    v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
+    v2 = fminf(fmaxf(v2, 0.0f), 1.0f);
+    if (o.rgb) { o.rgb[3 * pix] = v0; o.rgb[3 * pix + 1] = v1; o.rgb[3 * pix + 2] = v2; }
+    if (o.alpha) o.alpha[pix] = a;
+    if (o.depth) o.depth[pix] = ED;
+    if (o.rgb8) {
+        o.rgb8[3 * pix] = (uint8_t)(int)floorf(fma_(v0, 255.0f, 0.5f));
+        o.rgb8[3 * pix + 1] = (uint8_t)(int)floorf(fma_(v1, 255.0f, 0.5f));
+        o.rgb8[3 * pix + 2] = (uint8_t)(int)floorf(fma_(v2, 255.0f, 0.5f));
+    }
+    return ED;
+}
+
+// per-tile max of the expected depth (reduced over tiles by k_depth_fill); all threads call it
+DEV void store_tile_max(const SasFrame &f, int tile, float ED, unsigned *s_wmax)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float maxed = ED;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
+    if (lane == 0) s_wmax[wv] = __float_as_uint(maxed);
+    __syncthreads();
+    if (tid == 0) f.tile_max[tile] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    __syncthreads();
+}
+
+// ---- full path, stage 2: composite the complete sorted lists -----------------------------------
+template <bool FAST_EXP, bool WANT_MAX>
+__global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
+                                               const int *tl, const int *range)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];
+    __shared__ unsigned s_wmax[4];
+    const SasCam &c = P->cam;
+    const SasOutputs o = P->out;
+    BlendLds L;
+    L.q0 = reinterpret_cast<float4 *>(s_raw);
+    L.q1 = L.q0 + 256;
+    L.q2 = L.q1 + 256;
+    L.mask = reinterpret_cast<unsigned *>(L.q2 + 256);
+    L.queue = reinterpret_cast<unsigned short *>(L.mask + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
+        const int tile = tl[oi];
+        const int tx = tile % c.tw, ty = tile / c.tw;
+        const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
+        const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
+        const bool inside = ix < c.W && iy < c.H;
+        PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
+        bool wdone = __all(p.done);
+        const long long beg = f.tile_offset[tile];
+        long long end = f.tile_offset[tile + 1];
+        if (end > f.cap) end = f.cap;
+        const int *ids = f.sorted_ids + beg;
+        blend_range<FAST_EXP>(f, n_gauss, tx, ty, (float)ix + 0.5f, (float)iy + 0.5f, (int)(end - beg),
+                              [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
+        const float ED = write_pixel(o, p, inside, ix, iy, c.W);
+        if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+    }
+}
+
+// ================================================================================================
+// Production path: lazy depth ordering fused with compositing
+// ================================================================================================
+constexpr int kChunk = 1024;          // entries ordered and composited per round
+constexpr int kLazyThreads = 256;
+
+template <bool FAST_EXP, bool WANT_MAX>
+__global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
+                                                             const int *perm)
+{
+    // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
+    __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 15 KiB
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_wsum[4], s_wmax[4];
+    __shared__ unsigned s_mn, s_mx, s_m;
+    __shared__ int s_b1;
+    const SasCam &c = P->cam;
+    const SasOutputs o = P->out;
+    BlendLds L;
+    L.q0 = reinterpret_cast<float4 *>(s_raw);
+    L.q1 = L.q0 + 256;
+    L.q2 = L.q1 + 256;
+    L.mask = reinterpret_cast<unsigned *>(L.q2 + 256);
+    L.queue = reinterpret_cast<unsigned short *>(L.mask + 256);
+    unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
+    unsigned *dbase = cnt + 4 * 256;                              // [256]
+
+    const int tile = f.tile_order[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx = tile % c.tw, ty = tile / c.tw;
+    const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
+    const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
+    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const bool inside = ix < c.W && iy < c.H;
+    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
+    bool wdone = __all(p.done);
+
+    const long long beg = f.tile_offset[tile];
+    long long end = f.tile_offset[tile + 1];
+    if (end > f.cap) end = f.cap;
+    const int n = (int)(end - beg);
+    const unsigned long long *g = f.keys + beg;
+
+    if (n > 0 && n <= kChunk) {
+        // ---- short list: one pass, keys loaded once into registers, whole list is the chunk
+        constexpr int NK = kChunk / kLazyThreads;
+        if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
+        __syncthreads();
+        unsigned long long kk[NK];
+        unsigned mn = ~0u, mx = 0u;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int i = u * kLazyThreads + tid;
+            kk[u] = (i < n) ? g[i] : ~0ull;
+            if (i < n) { mn = min(mn, hi32(kk[u])); mx = max(mx, hi32(kk[u])); }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+        if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+        __syncthreads();
+        const unsigned dmin = s_mn, span = s_mx - s_mn;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int i = u * kLazyThreads + tid;
+            if (i < n) ck[i] = kk[u] - ((unsigned long long)dmin << 32);
+        }
+        __syncthreads();
+        lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
+        blend_range<FAST_EXP>(f, n_gauss, tx, ty, px, py, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+    } else if (n > kChunk) {
+        // ---- long list: every pass over the keys keeps U independent loads per thread in flight
+        constexpr int U = 8;
+        if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
+        s_hist[tid] = 0u;
+        __syncthreads();
+        unsigned mn = ~0u, mx = 0u;
+        for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+            unsigned dd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kLazyThreads + tid;
+                dd[u] = (i < n) ? hi32(g[i]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * kLazyThreads + tid < n) { mn = min(mn, dd[u]); mx = max(mx, dd[u]); }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+        if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+        __syncthreads();
+        const unsigned dmin = s_mn, span = s_mx - s_mn;
+        const int sbits = span ? 32 - __clz(span) : 0;
+        const int shift = sbits > 8 ? sbits - 8 : 0;   // 256 depth buckets over the tile's range
+        for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+            unsigned dd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kLazyThreads + tid;
+                dd[u] = (i < n) ? hi32(g[i]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * kLazyThreads + tid < n) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
+        }
+        __syncthreads();
+        int b_next = 0;
+        bool bail = false;
+        for (;;) {
+            // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
+            //      whose running count from b0 stays <= kChunk.  Thread t owns bucket t.
+            {
+                const unsigned hv = (tid >= b_next) ? s_hist[tid] : 0u;
+                unsigned incl = hv;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                if (lane == 63) s_wsum[wv] = incl;
+                __syncthreads();
+                for (int w = 0; w < wv; ++w) incl += s_wsum[w];        // inclusive count of buckets b_next..tid
+                const unsigned long long nz = __ballot(hv != 0u);
+                const unsigned long long fit = __ballot(hv != 0u && incl <= (unsigned)kChunk);
+                if (lane == 0) {
+                    s_queue_u32(s_raw)[wv] = nz ? (unsigned)(wv * 64 + __ffsll((long long)nz) - 1) : 256u;          // first non-empty
+                    s_queue_u32(s_raw)[4 + wv] = fit ? (unsigned)(wv * 64 + 63 - __clzll((long long)fit)) : 0xffffffffu;   // last fitting
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned first = 256u;
+                    int last = -1;
+                    for (int w = 3; w >= 0; --w) {
+                        if (s_queue_u32(s_raw)[w] != 256u) first = s_queue_u32(s_raw)[w];
+                    }
+                    for (int w = 0; w < 4; ++w)
+                        if (s_queue_u32(s_raw)[4 + w] != 0xffffffffu) last = (int)s_queue_u32(s_raw)[4 + w];
+                    s_m = first;
+                    s_b1 = (first >= 256u) ? 256 : last;   // last < first (i.e. -1): first bucket alone exceeds the chunk
+                }
+            }
+            __syncthreads();
+            const int b0 = (int)s_m, b1 = s_b1;
+            __syncthreads();
+            if (b1 == 256) break;                 // nothing left
+            if (b1 < 0) { bail = true; break; }   // one bucket larger than the chunk: full path
+            // ---- collect the range into LDS, depth words relative to the range's base
+            const unsigned base = dmin + ((unsigned)b0 << shift);
+            if (tid == 0) s_m = 0u;
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+                unsigned long long kk[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLazyThreads + tid;
+                    kk[u] = (i < n) ? g[i] : ~0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (i0 + u * kLazyThreads + tid < n) {
+                        const int b = (int)((hi32(kk[u]) - dmin) >> shift);
+                        if (b >= b0 && b <= b1) {
+                            const unsigned pos = atomicAdd(&s_m, 1u);
+                            ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int m = (int)s_m;
+            const unsigned long long hi_excl = ((unsigned long long)(b1 - b0 + 1) << shift);
+            const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
+            // ---- order the chunk, then composite it
+            lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
+            const bool all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, px, py, m,
+                                                        [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+            if (all_done) break;
+            b_next = b1 + 1;
+            if (b_next > 255) break;
+        }
+        if (bail) {
+            // hand the tile to the full path (k_sort_radix + k_blend over the fallback list), which
+            // starts it from scratch
+            if (tid == 0) f.fb_tiles[atomicAdd(&f.stats[6], 1u)] = tile;
+            return;
+        }
+    }
+    const float ED = write_pixel(o, p, inside, ix, iy, c.W);
+    if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+}
+
+// depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
+// Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
+// no same-address atomics.  ED >= 0, so the float order is the order of the bit patterns.
+__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *tile_max, int tiles, const SasParams *__restrict__ P)
+{
+    __shared__ unsigned s_max[4];
+    float *depth = P->out.depth;
+    const long long npix = (long long)P->cam.W * P->cam.H;
+    unsigned m = 0;
+    for (int t = threadIdx.x; t < tiles; t += 256) m = max(m, tile_max[t]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
+        if (depth[p] == 0.0f) depth[p] = mx;
+}
+
+// fallback range {0, count} from the counter the lazy kernel bumped
+__global__ void k_fb_range(SasFrame f)
+{
+    f.fb_range[0] = 0;
+    f.fb_range[1] = (int)f.stats[6];
+}
+
+}  // namespace
+
+// ---- launchers -------------------------------------------------------------------------------------
+constexpr int kSortMid = 4096, kSortLarge = 16384;
+
+// Full ordering of every tile.  class 0: >= 4096 (LDS up to 16384, longer lists in place),
+// class 1: 1024..4095, class 2: < 1024.  The classes are independent and each alone leaves most of
+// the chip idle (few long lists), so they run concurrently: classes 0 and 1 on two side streams
+// forked from / joined to `st`.
+void sas_launch_sort(hipStream_t st, const SasScene &s, int ntiles, const SasFrame &f, const SasSortStreams &ss)
+{
+    const unsigned tiles = (unsigned)ntiles;
+    hipStream_t s0 = st, s1 = st;
+    if (ss.side[0]) {
+        (void)hipEventRecord(ss.fork, st);
+        (void)hipStreamWaitEvent(ss.side[0], ss.fork, 0);
+        (void)hipStreamWaitEvent(ss.side[1], ss.fork, 0);
+        s0 = ss.side[0];
+        s1 = ss.side[1];
+    }
+    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(tiles), dim3(1024), 0, s0, f, s.perm, f.tile_order,
+                       f.sort_class + 0);
+    hipLaunchKernelGGL((k_sort_radix<kSortMid, 256, false>), dim3(tiles), dim3(256), 0, s1, f, s.perm, f.tile_order,
+                       f.sort_class + 1);
+    hipLaunchKernelGGL(k_sort_wave, dim3(tiles), dim3(64), 0, st, f, s.perm, f.tile_order, f.sort_class + 2);
+    if (ss.side[0]) {
+        (void)hipEventRecord(ss.join[0], s0);
+        (void)hipEventRecord(ss.join[1], s1);
+        (void)hipStreamWaitEvent(st, ss.join[0], 0);
+        (void)hipStreamWaitEvent(st, ss.join[1], 0);
+    }
+}
+
+template <bool FAST, bool WMAX>
+static void launch_blend_list(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n,
+                              const int *tl, const int *range)
+{
+    hipLaunchKernelGGL((k_blend<FAST, WMAX>), dim3(grid), dim3(256), 0, st, P, f, n, tl, range);
+}
+
+static void blend_list(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *tl,
+                       const int *range, bool fast_exp, bool want_max)
+{
+    if (fast_exp) {
+        if (want_max) launch_blend_list<true, true>(st, grid, P, f, n, tl, range);
+        else launch_blend_list<true, false>(st, grid, P, f, n, tl, range);
+    } else {
+        if (want_max) launch_blend_list<false, true>(st, grid, P, f, n, tl, range);
+        else launch_blend_list<false, false>(st, grid, P, f, n, tl, range);
+    }
+}
+
+// Full path, stage 2: composite all tiles from their complete lists (longest first).
+void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+                      bool fast_exp, bool want_max)
+{
+    const long long n = s.n > 0 ? s.n : 1;
+    blend_list(st, (unsigned)tiles, P, f, n, f.tile_order, f.sort_class + 4, fast_exp, want_max);
+}
+
+// Production path: lazy ordering + compositing, then the full path over the (normally empty) list
+// of tiles the lazy kernel handed back.
+void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+                           bool fast_exp, bool want_max)
+{
+    const unsigned grid = (unsigned)tiles;
+    const long long n = s.n > 0 ? s.n : 1;
+    if (fast_exp) {
+        if (want_max) hipLaunchKernelGGL((k_tile_lazy<true, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+        else hipLaunchKernelGGL((k_tile_lazy<true, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+    } else {
+        if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+        else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+    }
+    hipLaunchKernelGGL(k_fb_range, dim3(1), dim3(1), 0, st, f);
+    const unsigned fb_grid = grid < 256u ? grid : 256u;   // workgroups stride over the list
+    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(fb_grid), dim3(1024), 0, st, f, s.perm, f.fb_tiles,
+                       f.fb_range);
+    blend_list(st, fb_grid, P, f, n, f.fb_tiles, f.fb_range, fast_exp, want_max);
+}
+
+void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f)
+{
+    hipLaunchKernelGGL(k_depth_fill, dim3(1024), dim3(256), 0, st, (const unsigned *)f.tile_max, tiles, P);
+}

@@ -118,40 +118,52 @@ class Rasterizer:
                     "sas_set_group_poses")
 
     # -- frames -----------------------------------------------------------------------------
+    _SHAPES = {"rgb": (3, torch.float32), "alpha": (1, torch.float32), "depth": (1, torch.float32),
+               "rgb8": (3, torch.uint8)}
+
+    @staticmethod
+    def _host_f32(a, count: int) -> np.ndarray:
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.size == count):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(count)
+        return a
+
     def render(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
                background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb", "alpha", "depth"),
                depth_fill_max: bool = False, fast_exp: bool = False, timing: bool = False, block: bool = True,
-               out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+               full_sort: bool = False, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Render one view; returns device tensors ``rgb [H,W,3]``, ``alpha [H,W,1]``,
-        ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``."""
-        V = np.ascontiguousarray(np.asarray(viewmat.cpu() if isinstance(viewmat, torch.Tensor) else viewmat, dtype=np.float32)).reshape(16)
-        Kc = np.ascontiguousarray(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float32)).reshape(9)
-        bg = np.ascontiguousarray(np.asarray(background, dtype=np.float32)).reshape(3)
+        ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``.
+
+        ``block=False`` only enqueues (SAS_ASYNC): up to two frames are in flight, the result of a
+        frame is valid after ``wait()`` (work enqueued on the current stream after the NEXT
+        ``render`` call is also ordered behind it).  ``full_sort=True`` orders every tile list
+        completely and keeps it for ``read_tile_lists`` (same image, slower)."""
+        V = self._host_f32(viewmat, 16)
+        Kc = self._host_f32(K, 9)
+        bg = self._host_f32(background, 3)
         W, H = int(width), int(height)
-        want = tuple(want)
         res: Dict[str, torch.Tensor] = {}
-        shapes = {"rgb": ((H, W, 3), torch.float32), "alpha": ((H, W, 1), torch.float32),
-                  "depth": ((H, W, 1), torch.float32), "rgb8": ((H, W, 3), torch.uint8)}
+        ptrs = {"rgb": None, "alpha": None, "depth": None, "rgb8": None}
         for k in want:
-            if k not in shapes:
-                raise ValueError(f"unknown output {k!r}")
-            shp, dt = shapes[k]
-            if out is not None and k in out:
-                t = out[k]
-                if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
-                    raise ValueError(f"out[{k!r}] must be a contiguous {dt} tensor {shp} on {self.device}")
-            else:
-                t = torch.empty(shp, dtype=dt, device=self.device)
+            ch, dt = self._SHAPES[k]   # KeyError: unknown output
+            t = out.get(k) if out is not None else None
+            if t is None:
+                t = torch.empty((H, W, ch), dtype=dt, device=self.device)
+            elif t.shape != (H, W, ch) or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"out[{k!r}] must be a contiguous {dt} tensor {(H, W, ch)} on {self.device}")
             res[k] = t
-        ptr = lambda k: ctypes.c_void_p(res[k].data_ptr()) if k in res else None
+            ptrs[k] = t.data_ptr()
         flags = (_capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0) | (_capi.SAS_FAST_EXP if fast_exp else 0) | \
-                (_capi.SAS_TIMING if timing else 0) | (0 if block else _capi.SAS_ASYNC)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self._L.sas_render(self._ctx, V.ctypes.data_as(ctypes.c_void_p), Kc.ctypes.data_as(ctypes.c_void_p), W, H,
-                                bg.ctypes.data_as(ctypes.c_void_p), flags, ptr("rgb"), ptr("alpha"), ptr("depth"),
-                                ptr("rgb8"), stream)
-        self._check(rc, "sas_render")
-        self._keep = [] if block else (self._keep + [res])[-2:]
+                (_capi.SAS_TIMING if timing else 0) | (0 if block else _capi.SAS_ASYNC) | \
+                (_capi.SAS_FULL_SORT if full_sort else 0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._L.sas_render(self._ctx, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
+                                ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
+        if rc != 0:
+            self._check(rc, "sas_render")
+        self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
     def wait(self) -> None:

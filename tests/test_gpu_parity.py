@@ -21,9 +21,9 @@ def _upload(r, sc, **kw):
              group_id=kw.get("group_id"), n_groups=kw.get("n_groups", 0))
 
 
-def _compare(r, sc, cam, group_id=None, group_Rt=None, exact=True, depth_fill=False):
+def _compare(r, sc, cam, group_id=None, group_Rt=None, exact=True, depth_fill=False, full_sort=False):
     out = r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb", "alpha", "depth", "rgb8"),
-                   depth_fill_max=depth_fill)
+                   depth_fill_max=depth_fill, full_sort=full_sort)
     ref = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats,
                         scales=sc.scales, sh_degree=sc.sh_degree, group_id=group_id, group_Rt=group_Rt,
                         background=BG, depth_mode=1 if depth_fill else 0, want_rgb8=True, dump=True)
@@ -47,7 +47,8 @@ def test_projection_arrays_bit_exact(rasterizer):
     sc = make_scene(5000, seed=21, log_scale_mean=float(np.log(0.03)))
     cam = ring_camera(200, 120, 150.0, yaw_deg=15.0, elev=0.4)
     _upload(rasterizer, sc)
-    _, ref = _compare(rasterizer, sc, cam)
+    _compare(rasterizer, sc, cam)                              # production path: lazy per-tile ordering
+    _, ref = _compare(rasterizer, sc, cam, full_sort=True)     # full path: complete lists kept (T4/T5)
     p = rasterizer.read_projection()
     vis = (ref["radii"] > 0).all(axis=1)
     assert np.array_equal(p["radii"], ref["radii"])
@@ -161,7 +162,8 @@ def test_depth_ties_order_by_caller_index(rasterizer):
     sc.opacities[:] = np.clip(sc.opacities, 0.05, 0.5)
     cam = ring_camera(128, 96, 110.0)          # yaw 0: depth = 3 - z exactly
     _upload(rasterizer, sc)
-    _, ref = _compare(rasterizer, sc, cam)
+    _compare(rasterizer, sc, cam)
+    _, ref = _compare(rasterizer, sc, cam, full_sort=True)
     assert len(np.unique(ref["depths"][(ref["radii"] > 0).all(1)])) <= 3
     tl = rasterizer.read_tile_lists(cam.tiles)
     assert np.array_equal(tl["sorted_ids"], ref["sorted_ids"])
@@ -210,3 +212,34 @@ def test_every_sort_class_in_one_frame(rasterizer):
     _, ref = _compare(rasterizer, sc, cam)
     lens = np.diff(ref["tile_offsets"])
     assert (lens >= 4096).any() and ((lens >= 1024) & (lens < 4096)).any() and ((lens > 1) & (lens < 1024)).any()
+
+
+def test_lazy_and_full_paths_agree_and_fallback_is_exercised(rasterizer):
+    """20000 coplanar splats: every tile has far more than 1024 entries in ONE depth bucket, so the lazy
+    kernel hands the tiles to the full path; the image must not change, with or without SAS_FULL_SORT."""
+    rng = np.random.default_rng(21)
+    sc = make_scene(20000, seed=97, log_scale_mean=float(np.log(0.02)))
+    sc.means[:, 2] = 0.0
+    sc.means[:, :2] = rng.uniform(-0.5, 0.5, size=(sc.n, 2)).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.01, 0.05)
+    cam = ring_camera(96, 64, 90.0)
+    _upload(rasterizer, sc)
+    a, _ = _compare(rasterizer, sc, cam)
+    assert rasterizer.stats()["fallback_tiles"] > 0
+    b, _ = _compare(rasterizer, sc, cam, full_sort=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_lazy_multi_round_tiles(rasterizer):
+    """Long lists of nearly transparent splats: nothing saturates, so the lazy kernel has to walk
+    every depth bucket range of every tile (many rounds), still bit-exact."""
+    rng = np.random.default_rng(22)
+    sc = make_scene(40000, seed=98, log_scale_mean=float(np.log(0.01)))
+    sc.means[:] = rng.uniform(-0.4, 0.4, size=sc.means.shape).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.004, 0.01)
+    cam = ring_camera(80, 64, 110.0)
+    _upload(rasterizer, sc)
+    _compare(rasterizer, sc, cam)
+    st = rasterizer.stats()
+    assert st["max_tile_len"] > 4096 and st["fallback_tiles"] == 0
