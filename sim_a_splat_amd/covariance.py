@@ -1,0 +1,50 @@
+"""Gaussian activation and covariance assembly.
+
+``compute_cov`` serves sim_a_splat/ellipsoids/covariance_utils.py:152-157.  The reference goes
+quaternion -> angle-axis -> Rodrigues (with a +1e-6 in the denominator, :91); this is the closed
+form of the same rotation, equal to it within ~1e-6 and, unlike it, finite for a quaternion whose
+vector part is exactly zero (the reference returns NaN there: 0/0 * 0 in its mask blend, :54-57).
+"""
+from __future__ import annotations
+
+import torch
+
+C0 = 0.28209479177387814  # degree-0 SH basis (nerfstudio_utils.py:43)
+
+
+def sh2rgb(sh: torch.Tensor) -> torch.Tensor:
+    """Degree-0 colour, no clamp (nerfstudio_utils.py:46-47)."""
+    return sh * C0 + 0.5
+
+
+def quaternion_to_rotation_matrix(quat: torch.Tensor) -> torch.Tensor:
+    q = quat / torch.linalg.norm(quat, dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(q.shape[:-1] + (3, 3))
+
+
+def compute_cov(quat: torch.Tensor, scaling: torch.Tensor, exp: bool = False) -> torch.Tensor:
+    """Sigma = (R diag(s)) (R diag(s))^T  for [N,4] wxyz quaternions and [N,3] scales."""
+    s = torch.exp(scaling) if exp else scaling
+    M = quaternion_to_rotation_matrix(quat) * s.unsqueeze(-2)
+    return M @ M.transpose(-2, -1)
+
+
+class GSplatLoader:
+    """Activated Gaussians in the attribute layout of the reference's loader
+    (sim_a_splat/splat/splat_utils.py:24-49): ``means rots scales covs covs_inv colors opacities``."""
+
+    def __init__(self, means, quats, log_scales, features_dc, opacity_logits, device="cpu"):
+        dev = torch.device(device)
+        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        self.device = dev
+        self.means = f32(means)
+        self.rots = f32(quats)
+        self.scales = torch.exp(f32(log_scales))                     # :35-36
+        self.covs_inv = compute_cov(self.rots, 1.0 / self.scales)    # :38
+        self.covs = compute_cov(self.rots, self.scales)              # :39
+        self.colors = sh2rgb(f32(features_dc).reshape(-1, 3))        # :41
+        self.opacities = torch.sigmoid(f32(opacity_logits)).reshape(-1, 1)   # :43-45

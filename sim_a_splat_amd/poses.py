@@ -1,0 +1,97 @@
+"""Rigid/similarity pose algebra of the dynamic scene, pure NumPy float64.
+
+The reference does this with viser.transforms objects inside SplatHandler
+(sim_a_splat/splat/splat_handler.py:62-83, :227-314, :316-332).  Here poses are plain (R, t)
+pairs and every link pose is obtained by composing similarity transforms, which is the same
+algebra written once instead of term by term.
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import numpy as np
+
+
+def quat_wxyz_to_matrix(q: Sequence[float]) -> np.ndarray:
+    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def matrix_to_quat_wxyz(R: np.ndarray) -> np.ndarray:
+    R = np.asarray(R, dtype=np.float64)
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def decompose_icp(icp: np.ndarray, tol: float = 1e-6) -> Tuple[float, np.ndarray, np.ndarray]:
+    """Uniform scale, rotation and translation of the saved ICP 4x4 (splat_handler.py:66-83).
+    Raises ValueError where the reference asserts (non-uniform scale / shear)."""
+    A = np.asarray(icp, dtype=np.float64)[:3, :3]
+    G = A.T @ A
+    off = G[~np.eye(3, dtype=bool)]
+    if np.any(np.abs(off) >= tol):
+        raise ValueError("ICP matrix is not a scaled rotation (off-diagonal of R^T R)")
+    s2 = float(np.mean(np.diag(G)))
+    if np.any(np.abs(np.diag(G) - s2) >= tol):
+        raise ValueError("ICP matrix has non-uniform scale")
+    s = float(np.sqrt(s2))
+    return s, A / s, np.asarray(icp, dtype=np.float64)[:3, 3].copy()
+
+
+class Sim3:
+    """x -> s R x + t."""
+
+    def __init__(self, s: float, R: np.ndarray, t: np.ndarray):
+        self.s, self.R, self.t = float(s), np.asarray(R, np.float64), np.asarray(t, np.float64)
+
+    def __matmul__(self, o: "Sim3") -> "Sim3":
+        return Sim3(self.s * o.s, self.R @ o.R, self.s * self.R @ o.t + self.t)
+
+    def inv(self) -> "Sim3":
+        Rt = self.R.T
+        return Sim3(1.0 / self.s, Rt, -(Rt @ self.t) / self.s)
+
+
+def link_splat_pose(scale: float, Ri: np.ndarray, ti: np.ndarray, Rfk: np.ndarray, tfk: np.ndarray,
+                    q_msg: Sequence[float], p_msg: Sequence[float], weld_t=(0.0, 0.0, 0.0)) -> Tuple[np.ndarray, np.ndarray]:
+    """Pose (R, t) of one link's splat group for a Drake draw message (splat_handler.py:239-288).
+
+    The Gaussians of a link live in the splat frame, captured at the mask-time joint
+    configuration: x_splat = ICP(FK_link(x_link)).  Moving the link to the message pose M gives
+    x' = ICP(M(FK^-1(ICP^-1(x_splat)))), i.e. the group transform  ICP * M * FK^-1 * ICP^-1  with
+    ICP = (s, Ri, ti) a similarity and FK, M rigid.  Scales cancel, so the result is rigid.
+    """
+    icp = Sim3(scale, Ri, ti)
+    fk = Sim3(1.0, Rfk, tfk)
+    msg = Sim3(1.0, quat_wxyz_to_matrix(q_msg), np.asarray(p_msg, np.float64) + np.asarray(weld_t, np.float64))
+    g = icp @ msg @ fk.inv() @ icp.inv()
+    return g.R, g.t
+
+
+def attached_frame(scale: float, Ri: np.ndarray, ti: np.ndarray, q_link: Sequence[float], p_link: Sequence[float],
+                   local_xyz: Sequence[float]) -> Tuple[np.ndarray, np.ndarray]:
+    """Camera pose attached to a link (splat_handler.py:316-332).  As in the reference, the local
+    offset is ADDED to the link position in world axes (not rotated by the link) and then scaled."""
+    p = (np.asarray(p_link, np.float64) + np.asarray(local_xyz, np.float64)) * scale
+    return Ri @ quat_wxyz_to_matrix(q_link), Ri @ p + ti
+
+
+def rt_to_row12(R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    out = np.empty((3, 4), dtype=np.float32)
+    out[:, :3] = R
+    out[:, 3] = t
+    return out.reshape(12)
