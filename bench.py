@@ -39,9 +39,22 @@ def algorithmic_bytes(n, n_vis, m, w, h, out_bytes_per_pixel=12):
     return n * 236 + n_vis * 44 + m * 60 + w * h * out_bytes_per_pixel
 
 
-def blend_bytes(m, w, h, out_bytes_per_pixel=12):
-    """Dominant kernel (k_blend): gather of M sorted entries (id 4 B + record 40 B) + the frame."""
-    return m * 44 + w * h * out_bytes_per_pixel
+def tile_kernel_bytes(m, w, h, out_bytes_per_pixel=12):
+    """Dominant kernel (k_tile_lazy = per-tile ordering + compositing), SURVEY.md 8d terms:
+    8 B key read per intersection + 44 B gather per intersection (id 4 + record 40) + the frame."""
+    return m * (8 + 44) + w * h * out_bytes_per_pixel
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no summary is committed."""
+    p = ROOT / "profiles" / "hbm_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        return json.loads(p.read_text())["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(scene, cam, budget_s=20.0):
@@ -128,7 +141,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         fps = world * a.steps / elapsed
-        achieved = blend_bytes(st["n_isect"], W, H) / blend_s / 1e9
+        achieved = tile_kernel_bytes(st["n_isect"], W, H) / blend_s / 1e9
         frame_bytes = algorithmic_bytes(scene.n, st["n_visible"], st["n_isect"], W, H)
         line = {
             "metric": "rendered frames/sec at 1M Gaussians 1920x1080",
@@ -139,8 +152,8 @@ def main():
                                    "fx=fy=1000, one view per GPU, float32 RGB out",
                        "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
                        "views_per_step": world, "parallelism": f"views{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy"),
                          "kernel_ms": blend_s * 1e3,
                          "frame_algorithmic_GBps": frame_bytes / (elapsed / a.steps) / 1e9,
                          "frame_frac": frame_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS,

@@ -48,7 +48,9 @@ typedef enum {
 #define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */
 
 /* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
-enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT, SAS_T_BLEND, SAS_T_TOTAL, SAS_T_COUNT };
+enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path only */,
+       SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* fallback tiles, depth fill */,
+       SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,

@@ -18,7 +18,7 @@ SAS_FAST_EXP = 4
 SAS_TIMING = 8
 SAS_FULL_SORT = 16
 
-STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "total")
+STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "tail", "total")
 STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles")
 
 # every symbol include/sim_a_splat_amd.h declares

@@ -101,7 +101,7 @@ struct sas_ctx {
     uint64_t scene_version = 0;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
-    float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0};
+    float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -272,8 +272,10 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
-    if (fill) sas_launch_depth_fill(st, tiles, P, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
+    if (!full) sas_launch_fallback(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
+    if (fill) sas_launch_depth_fill(st, tiles, P, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return SAS_OK;
 }
@@ -378,8 +380,8 @@ int complete_oldest(sas_ctx *c)
         c->stats[SAS_S_WINDOW_MISSES] = s[5];
         c->stats[SAS_S_FALLBACK_TILES] = s[6];
         if (sl.timed) {
-            for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
-            (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[5]);
+            for (int k = 0; k < 6; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
+            (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[6]);
         }
         if (!s[2]) {
             // later work on the caller's stream is ordered after this frame

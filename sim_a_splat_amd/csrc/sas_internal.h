@@ -91,4 +91,6 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
                       bool fast_exp, bool want_max);
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                            bool fast_exp, bool want_max);
+void sas_launch_fallback(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+                         bool fast_exp, bool want_max);
 void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f);

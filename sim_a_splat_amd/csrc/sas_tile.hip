@@ -854,8 +854,7 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
     blend_list(st, (unsigned)tiles, P, f, n, f.tile_order, f.sort_class + 4, fast_exp, want_max);
 }
 
-// Production path: lazy ordering + compositing, then the full path over the (normally empty) list
-// of tiles the lazy kernel handed back.
+// Production path: lazy ordering + compositing of every tile in one launch.
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                            bool fast_exp, bool want_max)
 {
@@ -868,8 +867,15 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
         if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
         else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
     }
+}
+
+// The full path over the (normally empty) list of tiles the lazy kernel handed back.
+void sas_launch_fallback(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+                         bool fast_exp, bool want_max)
+{
+    const long long n = s.n > 0 ? s.n : 1;
     hipLaunchKernelGGL(k_fb_range, dim3(1), dim3(1), 0, st, f);
-    const unsigned fb_grid = grid < 256u ? grid : 256u;   // workgroups stride over the list
+    const unsigned fb_grid = (unsigned)tiles < 256u ? (unsigned)tiles : 256u;   // workgroups stride over the list
     hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(fb_grid), dim3(1024), 0, st, f, s.perm, f.fb_tiles,
                        f.fb_range);
     blend_list(st, fb_grid, P, f, n, f.fb_tiles, f.fb_range, fast_exp, want_max);
