@@ -388,6 +388,7 @@ struct PixState {
     float T, r, g, b, d;
     bool done;
 };
+typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 // exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
 // the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
@@ -517,7 +518,13 @@ DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int i
     v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
     v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
     v2 = fminf(fmaxf(v2, 0.0f), 1.0f);
-    if (o.rgb) { o.rgb[3 * pix] = v0; o.rgb[3 * pix + 1] = v1; o.rgb[3 * pix + 2] = v2; }
+    // one 12-byte store per pixel: a wave's 8-pixel rows are then whole 96-byte runs instead of
+    // three passes of strided 4-byte stores over the same lines
+    if (o.rgb) {
+        // (hipcc splits a plain 12-byte struct store here into three dword stores)
+        const f32x3 v = {v0, v1, v2};
+        asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(o.rgb + 3 * pix), "v"(v) : "memory");
+    }
     if (o.alpha) o.alpha[pix] = a;
     if (o.depth) o.depth[pix] = ED;
     if (o.rgb8) {
