@@ -15,6 +15,8 @@
 // Both paths composite through the same code (blend_range) and therefore produce identical bits.
 #include "sas_device.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -384,9 +386,13 @@ DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B,
     return m;
 }
 
+// Per-pixel compositing state.  A terminated pixel (transmittance test fired, or outside the image)
+// is parked at x = kDeadPx: every later sigma is then huge or NaN and fails `sigma <= thr` by
+// itself, so the inner loop carries no "done" flag.
+constexpr float kDeadPx = 1.0e30f;
 struct PixState {
     float T, r, g, b, d;
-    bool done;
+    float px;
 };
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
@@ -406,30 +412,28 @@ DEV float c_expf_neg_small(float x)
     return __builtin_ldexpf(p, (int)n);
 }
 
-// `cand` = pixel alive, sigma >= 0 and sigma <= thr.  sigma > thr implies alpha < 1/255 with a
-// margin far above rounding, so excluding those lanes takes the same decision as the contract.
+// One splat onto one pixel.  `cand` = sigma >= 0 and sigma <= thr (sigma > thr implies
+// alpha < 1/255 with a margin far above rounding: same decision as the contract's alpha test).
+// Returns true when the pixel terminated on this splat (T' <= 1e-4: the splat is not added).
 template <bool FAST_EXP>
-DEV void blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
+DEV bool blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
 {
-    if (cand) {
-        float E;
-        if (FAST_EXP) E = __expf(-sigma);
-        else E = c_expf_neg_small(-sigma);
-        const float alpha = fminf(kMaxAlpha, op * E);
-        if (!(alpha < kAlphaThr)) {
-            const float nT = p.T * (1.0f - alpha);
-            if (nT <= kTStop) {
-                p.done = true;
-            } else {
-                const float vis = alpha * p.T;
-                p.r = fma_(cr, vis, p.r);
-                p.g = fma_(cg, vis, p.g);
-                p.b = fma_(cb, vis, p.b);
-                p.d = fma_(dep, vis, p.d);
-                p.T = nT;
-            }
-        }
-    }
+    float E;
+    if (FAST_EXP) E = __expf(-sigma);
+    else E = c_expf_neg_small(-sigma);
+    const float alpha = fminf(kMaxAlpha, op * E);
+    const bool keep = cand && !(alpha < kAlphaThr);
+    const float nT = p.T * (1.0f - alpha);
+    const bool stop = keep && (nT <= kTStop);
+    const bool upd = keep && !stop;
+    const float vis = alpha * p.T;
+    p.r = upd ? fma_(cr, vis, p.r) : p.r;
+    p.g = upd ? fma_(cg, vis, p.g) : p.g;
+    p.b = upd ? fma_(cb, vis, p.b) : p.b;
+    p.d = upd ? fma_(dep, vis, p.d) : p.d;
+    p.T = upd ? nT : p.T;
+    p.px = stop ? kDeadPx : p.px;
+    return stop;
 }
 
 // LDS of the compositing loop: one staged batch of 256 records + per-wave compacted queues.
@@ -447,7 +451,7 @@ constexpr int kBlendLdsBytes = 3 * 256 * 16 + 256 * 4 + 4 * 256 * 2;   // 15360
 // tile has terminated (uniform over the workgroup).  `slot_at(i)` gives the storage slot of
 // entry i.
 template <bool FAST_EXP, typename SlotAt>
-DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float px, float py, int count, SlotAt slot_at,
+DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float py, int count, SlotAt slot_at,
                      const BlendLds &L, PixState &p, bool &wdone)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -490,16 +494,17 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
             }
             for (int k = 0; k < qn; ++k) {
                 const int e = queue[k];
-                const float4 A = L.q0[e], B = L.q1[e], C = L.q2[e];
-                const float dx = A.x - px, dy = A.y - py;
+                const float4 A = L.q0[e], B = L.q1[e];
+                const float dx = A.x - p.px, dy = A.y - py;
                 const float sg = fma_(0.5f, fma_(B.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
-                const bool cand = !p.done && sg >= 0.0f && sg <= B.z;
+                const bool cand = sg >= 0.0f && sg <= B.z;
                 if (__any(cand)) {
-                    blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
-                    if (__all(p.done)) break;
+                    const float4 C = L.q2[e];
+                    const bool stop = blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
+                    if (__any(stop) && __all(p.px >= kDeadPx)) break;
                 }
             }
-            wdone = __all(p.done);
+            wdone = __all(p.px >= kDeadPx);
         }
     }
     if (!all_done) all_done = __syncthreads_and(wdone);   // also fences the staging buffers
@@ -570,13 +575,13 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
         const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
         const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
         const bool inside = ix < c.W && iy < c.H;
-        PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
-        bool wdone = __all(p.done);
+        PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+        bool wdone = __all(!inside);
         const long long beg = f.tile_offset[tile];
         long long end = f.tile_offset[tile + 1];
         if (end > f.cap) end = f.cap;
         const int *ids = f.sorted_ids + beg;
-        blend_range<FAST_EXP>(f, n_gauss, tx, ty, (float)ix + 0.5f, (float)iy + 0.5f, (int)(end - beg),
+        blend_range<FAST_EXP>(f, n_gauss, tx, ty, (float)iy + 0.5f, (int)(end - beg),
                               [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
         const float ED = write_pixel(o, p, inside, ix, iy, c.W);
         if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
@@ -591,7 +596,7 @@ constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
 __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
-                                                             const int *perm)
+                                                             const int *perm, int ablate)
 {
     // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
     __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
@@ -616,10 +621,10 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
     const int tx = tile % c.tw, ty = tile / c.tw;
     const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
     const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
-    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const float py = (float)iy + 0.5f;
     const bool inside = ix < c.W && iy < c.H;
-    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, !inside};
-    bool wdone = __all(p.done);
+    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+    bool wdone = __all(!inside);
 
     const long long beg = f.tile_offset[tile];
     long long end = f.tile_offset[tile + 1];
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
             if (i < n) ck[i] = kk[u] - ((unsigned long long)dmin << 32);
         }
         __syncthreads();
-        lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
-        blend_range<FAST_EXP>(f, n_gauss, tx, ty, px, py, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+        if (!(ablate & 1)) lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
+        if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
     } else if (n > kChunk) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
         constexpr int U = 8;
@@ -757,9 +762,11 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
             const unsigned long long hi_excl = ((unsigned long long)(b1 - b0 + 1) << shift);
             const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
             // ---- order the chunk, then composite it
-            lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
-            const bool all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, px, py, m,
-                                                        [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+            if (!(ablate & 1)) lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
+            bool all_done = true;   // ablation (debug, SAS_ABLATE): pretend the first chunk saturates
+            if (!(ablate & 2))
+                all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, m,
+                                                 [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
             if (all_done) break;
             b_next = b1 + 1;
             if (b_next > 255) break;
@@ -867,12 +874,13 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
 {
     const unsigned grid = (unsigned)tiles;
     const long long n = s.n > 0 ? s.n : 1;
+    static const int ablate = getenv("SAS_ABLATE") ? atoi(getenv("SAS_ABLATE")) : 0;   // timing experiments only
     if (fast_exp) {
-        if (want_max) hipLaunchKernelGGL((k_tile_lazy<true, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
-        else hipLaunchKernelGGL((k_tile_lazy<true, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+        if (want_max) hipLaunchKernelGGL((k_tile_lazy<true, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
+        else hipLaunchKernelGGL((k_tile_lazy<true, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
     } else {
-        if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
-        else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm);
+        if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
+        else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
     }
 }
 
