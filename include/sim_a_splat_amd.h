@@ -49,13 +49,13 @@ typedef enum {
 
 /* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
 enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path only */,
-       SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* fallback tiles, depth fill */,
+       SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* depth fill */,
        SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
-       SAS_S_FALLBACK_TILES /* tiles the lazy tile kernel handed to the full sort path */, SAS_S_COUNT };
+       SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);

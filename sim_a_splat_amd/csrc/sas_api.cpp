@@ -235,8 +235,6 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
     f.tile_cursor = (int *)q.tilebuf.p + (tiles + 1);
     f.tile_order = (int *)q.tilebuf.p + (2 * tiles + 1);
     f.sort_class = (int *)q.tilebuf.p + (3 * tiles + 1);
-    f.fb_range = (int *)q.tilebuf.p + (3 * tiles + 1) + 6;
-    f.fb_tiles = (int *)q.tilebuf.p + (3 * tiles + 1) + 8;
     f.keys = (unsigned long long *)q.keys.p;
     f.sorted_ids = (int *)q.ids.p;
     f.cap = q.cap;
@@ -273,7 +271,6 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
-    if (!full) sas_launch_fallback(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     if (fill) sas_launch_depth_fill(st, tiles, P, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));

@@ -41,7 +41,7 @@ struct SasScene {
 //   info[n]        (x0 | x1<<16, y0 | y1<<16, depth bits, rx | ry<<16): tile rectangle, 0 if culled
 //   stats          [0] n_visible [1] n_isect [2] overflow [3] max ED bits [4] max tile length
 //                  [5] workgroups whose screen window did not fit the LDS histogram (direct atomics)
-//                  [6] tiles handed from the lazy tile kernel to the full sort + blend path
+//                  [6] tiles the lazy kernel had to order completely (one depth bucket > chunk)
 struct SasFrame {
     float4 *rec;
     uint4 *info;
@@ -50,8 +50,6 @@ struct SasFrame {
     int *tile_cursor;  // [tiles]
     int *tile_order;   // [tiles] tiles by descending list length (blend launch order)
     int *sort_class;   // [6] starts of the large / mid / small sort class in tile_order, tiles; then {0, tiles}
-    int *fb_tiles;     // [tiles] tiles the lazy kernel handed to the full path (count in stats[6])
-    int *fb_range;     // [2] {0, count}
     unsigned long long *keys;  // [cap]  depth bits << 32 | caller index
     int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
@@ -91,6 +89,4 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
                       bool fast_exp, bool want_max);
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                            bool fast_exp, bool want_max);
-void sas_launch_fallback(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                         bool fast_exp, bool want_max);
 void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f);

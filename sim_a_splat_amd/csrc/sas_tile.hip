@@ -7,10 +7,10 @@
 // pulls the nearest <= 1024 entries into LDS, radix-sorts only that chunk, composites it, and
 // fetches the next buckets only while some pixel is still alive.
 //
-// Full path (k_sort_* + k_blend): orders every list completely and writes the per-tile lists to
-// memory, exactly the T4/T5 products of the reference (read back by sas_read_tile_lists for the
-// parity tests).  It is also the fallback for the rare tile the lazy kernel gives up on (more
-// than 1024 entries inside one depth bucket, e.g. thousands of coplanar splats).
+// Full path (k_sort_* + k_blend, SAS_FULL_SORT): orders every list completely and writes the
+// per-tile lists to memory, exactly the T4/T5 products of the reference (read back by
+// sas_read_tile_lists for the parity tests).  A tile with more than 1024 entries inside one depth
+// bucket (e.g. thousands of coplanar splats) is ordered in place by the lazy kernel itself.
 //
 // Both paths composite through the same code (blend_range) and therefore produce identical bits.
 #include "sas_device.h"
@@ -772,10 +772,15 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
             if (b_next > 255) break;
         }
         if (bail) {
-            // hand the tile to the full path (k_sort_radix + k_blend over the fallback list), which
-            // starts it from scratch
-            if (tid == 0) f.fb_tiles[atomicAdd(&f.stats[6], 1u)] = tile;
-            return;
+            // More than kChunk entries in one depth bucket (e.g. thousands of coplanar splats): order
+            // the whole segment in place (slow, rare) and composite it from scratch.
+            if (tid == 0) atomicAdd(&f.stats[6], 1u);
+            int *out = f.sorted_ids + beg;
+            sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
+            __syncthreads();
+            p = PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+            wdone = __all(!inside);
+            blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
         }
     }
     const float ED = write_pixel(o, p, inside, ix, iy, c.W);
@@ -799,13 +804,6 @@ __global__ __launch_bounds__(256) void k_depth_fill(const unsigned *tile_max, in
     const float mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
         if (depth[p] == 0.0f) depth[p] = mx;
-}
-
-// fallback range {0, count} from the counter the lazy kernel bumped
-__global__ void k_fb_range(SasFrame f)
-{
-    f.fb_range[0] = 0;
-    f.fb_range[1] = (int)f.stats[6];
 }
 
 }  // namespace
@@ -882,18 +880,6 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
         if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
         else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
     }
-}
-
-// The full path over the (normally empty) list of tiles the lazy kernel handed back.
-void sas_launch_fallback(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                         bool fast_exp, bool want_max)
-{
-    const long long n = s.n > 0 ? s.n : 1;
-    hipLaunchKernelGGL(k_fb_range, dim3(1), dim3(1), 0, st, f);
-    const unsigned fb_grid = (unsigned)tiles < 256u ? (unsigned)tiles : 256u;   // workgroups stride over the list
-    hipLaunchKernelGGL((k_sort_radix<kSortLarge, 1024, true>), dim3(fb_grid), dim3(1024), 0, st, f, s.perm, f.fb_tiles,
-                       f.fb_range);
-    blend_list(st, fb_grid, P, f, n, f.fb_tiles, f.fb_range, fast_exp, want_max);
 }
 
 void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f)
