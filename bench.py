@@ -102,23 +102,28 @@ def main():
         out = bufs[i % 3]
         r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=out, block=False,
                  timing=timing)
-        if world > 1:
-            gather.start(out["rgb"])   # behind this frame on the stream; overlaps the next render
+        # After render(i) returns, the current stream is ordered behind frame i-1 (C ABI contract):
+        # gather that one, so the xGMI transfer of frame i-1 overlaps the rendering of frame i.
+        if world > 1 and i > 0:
+            gather.start(bufs[(i - 1) % 3]["rgb"])
 
-    def sync():
-        r.wait()
-        gather.finish()
+    def sync(last_i):
+        r.wait()                       # orders the current stream behind every frame
+        if world > 1:
+            if last_i >= 0:
+                gather.start(bufs[last_i % 3]["rgb"])
+            gather.finish()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
     for i in range(a.warmup):
         step(i, False)
-    sync()
+    sync(a.warmup - 1)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, False)
-    sync()
+    sync(a.steps - 1)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

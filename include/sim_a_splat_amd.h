@@ -42,7 +42,8 @@ typedef enum {
 
 /* sas_render flags */
 #define SAS_DEPTH_FILL_MAX 1u /* depth = where(alpha > 0, ED, max(ED)): nerfstudio get_outputs (T0) */
-#define SAS_ASYNC 2u          /* enqueue only; results valid after sas_wait() */
+#define SAS_ASYNC 2u          /* enqueue only (<= 2 frames in flight); results valid after sas_wait(); work put on
+                                 `stream` after sas_render(i) returns is ordered behind frame i-1 */
 #define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
 #define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
 #define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */

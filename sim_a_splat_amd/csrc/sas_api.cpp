@@ -46,8 +46,8 @@ struct Scratch {
 // concurrent sort classes) and its own scratch: the stages of a frame are each too short on
 // parallelism to fill 256 CUs (a few thousand tiles), so consecutive frames overlap on the chip.
 // The internal stream starts after everything the caller had enqueued on `stream` at the time of
-// sas_render; the caller's stream is made to wait for a frame when the NEXT frame is submitted
-// (or in sas_wait), which keeps exactly two frames in flight.
+// sas_render; the caller's stream is made to wait for frame i when frame i+1 is submitted (or in
+// sas_wait), which keeps two frames in flight.
 struct Slot {
     RenderArgs args;
     hipStream_t fs = nullptr;
@@ -639,6 +639,13 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     a.valid = true;
     int rc = enqueue_frame(c, sl);
     if (rc) return rc;
+    // Work the caller enqueues on `stream` from now on is ordered behind the PREVIOUS frame (a
+    // stream wait, no host synchronisation): a consumer can run one frame behind the renderer
+    // while this frame overlaps the previous one on the GPU.
+    if (c->inflight > 0) {
+        Slot &prev = c->slots[(si + c->n_slots - 1) % c->n_slots];
+        if (prev.busy) HIP_TRY(c, hipStreamWaitEvent(st, prev.done, 0));
+    }
     c->inflight++;
     c->last_slot = si;
     if (flags & SAS_ASYNC) return SAS_OK;

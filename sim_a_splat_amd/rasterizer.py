@@ -137,8 +137,8 @@ class Rasterizer:
         ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``.
 
         ``block=False`` only enqueues (SAS_ASYNC): up to two frames are in flight, the result of a
-        frame is valid after ``wait()`` (work enqueued on the current stream after the NEXT
-        ``render`` call is also ordered behind it).  ``full_sort=True`` orders every tile list
+        frame is valid after ``wait()``; work enqueued on the current stream after ``render`` of frame
+        i returns is ordered behind frame i-1.  ``full_sort=True`` orders every tile list
         completely and keeps it for ``read_tile_lists`` (same image, slower)."""
         V = self._host_f32(viewmat, 16)
         Kc = self._host_f32(K, 9)
