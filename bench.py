@@ -87,8 +87,9 @@ def main():
     rank, world, local_rank = sdist.init_from_env()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("SAS_FORCE_DEVICE", local_rank))   # rehearsal on a 1-GPU box only
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     W, H = 1920, 1080
     scene = make_scene(a.gaussians, seed=3, log_scale_mean=float(np.log(0.006)))

@@ -25,9 +25,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SAS_DIST_BACKEND=gloo is for rehearsing the multi-rank path on a box with one GPU
+            backend = os.environ.get("SAS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(int(os.environ.get("SAS_FORCE_DEVICE", local_rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -49,12 +50,15 @@ class FrameGather:
         self.world, self.rank, self.dst = world, rank, dst
         self._work = None
         self._bufs: Optional[List[torch.Tensor]] = None
+        self._via_host = world > 1 and dist.get_backend() == "gloo"   # gloo cannot gather device tensors
 
     def start(self, frame: torch.Tensor):
         if self.world <= 1:
             self._bufs = [frame]
             return
         self.finish()
+        if self._via_host and frame.is_cuda:
+            frame = frame.cpu()
         gl = None
         if self.rank == self.dst:
             if self._bufs is None or self._bufs[0].shape != frame.shape or self._bufs[0].dtype != frame.dtype:
