@@ -426,11 +426,13 @@ DEV bool blend_one(PixState &p, bool cand, float sigma, float op, float cr, floa
     const float nT = p.T * (1.0f - alpha);
     const bool stop = keep && (nT <= kTStop);
     const bool upd = keep && !stop;
-    const float vis = alpha * p.T;
-    p.r = upd ? fma_(cr, vis, p.r) : p.r;
-    p.g = upd ? fma_(cg, vis, p.g) : p.g;
-    p.b = upd ? fma_(cb, vis, p.b) : p.b;
-    p.d = upd ? fma_(dep, vis, p.d) : p.d;
+    // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite colours and
+    // depths of the path, so one select on the weight replaces four on the accumulators
+    const float vis = upd ? alpha * p.T : 0.0f;
+    p.r = fma_(cr, vis, p.r);
+    p.g = fma_(cg, vis, p.g);
+    p.b = fma_(cb, vis, p.b);
+    p.d = fma_(dep, vis, p.d);
     p.T = upd ? nT : p.T;
     p.px = stop ? kDeadPx : p.px;
     return stop;
@@ -748,12 +750,19 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    // wave-aggregated append: one LDS atomic per wave instead of 64 on one address
+                    bool sel = false;
                     if (i0 + u * kLazyThreads + tid < n) {
                         const int b = (int)((hi32(kk[u]) - dmin) >> shift);
-                        if (b >= b0 && b <= b1) {
-                            const unsigned pos = atomicAdd(&s_m, 1u);
-                            ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
-                        }
+                        sel = b >= b0 && b <= b1;
+                    }
+                    const unsigned long long sm = __ballot(sel);
+                    if (sm) {
+                        unsigned wbase = 0u;
+                        if (lane == 0) wbase = atomicAdd(&s_m, (unsigned)__popcll(sm));
+                        wbase = __shfl(wbase, 0);
+                        if (sel) ck[wbase + (unsigned)__popcll(sm & ((1ull << lane) - 1ull))] =
+                            ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
                     }
                 }
             }
