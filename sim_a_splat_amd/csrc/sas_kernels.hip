@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__
     if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = s_nvis;
 }
 
-// ---- k_scan: exclusive scan over tiles (one workgroup) ------------------------------------------
+// ---- k_scan: exclusive scan over tiles (workgroup 0) + tile order (workgroup 1) -------------------
 // Each thread owns 8 consecutive tiles per round and loads them before anything else, so a round
 // costs one memory latency (the counts were written by memory-side atomics and miss every cache).
 // Also: blend launch order (tiles bucketed by floor(log2(length)), longest first, so long lists
@@ -367,13 +367,64 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
     __shared__ int s_bucket[33];
     __shared__ int s_bbase[33];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 33) s_bucket[tid] = 0;
-    int nvis = 0;
-    for (int i = tid; i < f.n_wg; i += 1024) nvis += f.wg_vis[i];
-    __syncthreads();
-    int carry = 0, maxlen = 0;
     const int rounds = (tiles + 1024 * kScanPer - 1) / (1024 * kScanPer);
-    // pass 1: offsets + bucket histogram
+
+    if (blockIdx.x == 1) {
+        // ---- workgroup 1: blend launch order and sort classes (independent of the offsets)
+        if (tid < 33) s_bucket[tid] = 0;
+        __syncthreads();
+        int v0[kScanPer];
+        for (int r = 0; r < rounds; ++r) {
+            const int base = (r * 1024 + tid) * kScanPer;
+            int v[kScanPer];
+#pragma unroll
+            for (int k = 0; k < kScanPer; ++k) v[k] = (base + k < tiles) ? f.tile_count[base + k] : 0;
+            if (r == 0) {
+#pragma unroll
+                for (int k = 0; k < kScanPer; ++k) v0[k] = v[k];
+            }
+#pragma unroll
+            for (int k = 0; k < kScanPer; ++k)
+                if (base + k < tiles) atomicAdd(&s_bucket[v[k] ? 32 - __clz(v[k]) : 0], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int bkt = 32; bkt >= 0; --bkt) { s_bbase[bkt] = run; run += s_bucket[bkt]; }
+            // bucket b holds lengths [2^(b-1), 2^b): sort classes are bucket ranges, hence contiguous
+            f.sort_class[0] = 0;             // large: length >= 4096 (buckets >= 13)
+            f.sort_class[1] = s_bbase[12];   // mid:   1024..4095     (buckets 11, 12)
+            f.sort_class[2] = s_bbase[10];   // small: < 1024         (buckets <= 10)
+            f.sort_class[3] = tiles;
+            f.sort_class[4] = 0;             // every tile, for the full-path blend
+            f.sort_class[5] = tiles;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const int base = (r * 1024 + tid) * kScanPer;
+#pragma unroll
+            for (int k = 0; k < kScanPer; ++k)
+                if (base + k < tiles) {
+                    const int v = (r == 0) ? v0[k] : f.tile_count[base + k];
+                    f.tile_order[atomicAdd(&s_bbase[v ? 32 - __clz(v) : 0], 1)] = base + k;
+                }
+        }
+        return;
+    }
+
+    // ---- workgroup 0: offsets, scatter cursors, visible count, max list length, overflow flag
+    int nvis = 0;
+    for (int i0 = 0; i0 < f.n_wg; i0 += 1024 * 8) {
+        int part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024 + tid;
+            part[u] = (i < f.n_wg) ? f.wg_vis[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nvis += part[u];
+    }
+    int carry = 0, maxlen = 0;
     for (int r = 0; r < rounds; ++r) {
         const int base = (r * 1024 + tid) * kScanPer;
         int v[kScanPer];
@@ -384,7 +435,6 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         for (int k = 0; k < kScanPer; ++k) {
             sum += v[k];
             maxlen = max(maxlen, v[k]);
-            if (base + k < tiles) atomicAdd(&s_bucket[v[k] ? 32 - __clz(v[k]) : 0], 1);
         }
         int incl = sum;
 #pragma unroll
@@ -409,29 +459,6 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
         }
         carry += total;
         __syncthreads();
-    }
-    // bucket bases, longest lists first
-    if (tid == 0) {
-        int run = 0;
-        for (int bkt = 32; bkt >= 0; --bkt) { s_bbase[bkt] = run; run += s_bucket[bkt]; }
-        // bucket b holds lengths [2^(b-1), 2^b): sort classes are bucket ranges, hence contiguous
-        f.sort_class[0] = 0;             // large: length >= 4096 (buckets >= 13)
-        f.sort_class[1] = s_bbase[12];   // mid:   1024..4095     (buckets 11, 12)
-        f.sort_class[2] = s_bbase[10];   // small: < 1024         (buckets <= 10)
-        f.sort_class[3] = tiles;
-        f.sort_class[4] = 0;             // every tile, for the full-path blend
-        f.sort_class[5] = tiles;
-    }
-    __syncthreads();
-    // pass 2: placement (counts are L2-resident now)
-    for (int r = 0; r < rounds; ++r) {
-        const int base = (r * 1024 + tid) * kScanPer;
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k)
-            if (base + k < tiles) {
-                const int v = f.tile_count[base + k];
-                f.tile_order[atomicAdd(&s_bbase[v ? 32 - __clz(v) : 0], 1)] = base + k;
-            }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -525,7 +552,7 @@ void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, c
 
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, f, tiles);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, st, f, tiles);
 }
 
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f)
