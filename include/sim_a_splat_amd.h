@@ -46,6 +46,7 @@ typedef enum {
                                  `stream` after sas_render(i) returns is ordered behind frame i-1 */
 #define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
 #define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
+#define SAS_TIME_TILES 32u    /* HIP events around the tile kernel only (SAS_T_BLEND); frames still pipeline */
 #define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */
 
 /* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
@@ -105,6 +106,9 @@ int sas_wait(sas_ctx *ctx);
 
 const char *sas_last_error(sas_ctx *ctx);
 int sas_stage_times(sas_ctx *ctx, float *ms, int n);
+/* Mean stage times over the frames completed with SAS_TIMING / SAS_TIME_TILES since the last reset
+ * (slots without events read 0); *frames receives the number of frames averaged. */
+int sas_stage_time_means(sas_ctx *ctx, float *ms, int n, int64_t *frames, int reset);
 int sas_frame_stats(sas_ctx *ctx, int64_t *stats, int n);
 
 /* Parity hooks (HOST output pointers, any may be NULL): per-Gaussian projection results and the

@@ -17,6 +17,7 @@ SAS_ASYNC = 2
 SAS_FAST_EXP = 4
 SAS_TIMING = 8
 SAS_FULL_SORT = 16
+SAS_TIME_TILES = 32
 
 STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "tail", "total")
 STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles")
@@ -24,7 +25,7 @@ STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "wi
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (
     "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_render", "sas_wait",
-    "sas_last_error", "sas_stage_times", "sas_frame_stats", "sas_read_projection", "sas_read_tile_lists",
+    "sas_last_error", "sas_stage_times", "sas_stage_time_means", "sas_frame_stats", "sas_read_projection", "sas_read_tile_lists",
     "sas_version",
 )
 
@@ -55,6 +56,7 @@ def lib() -> ctypes.CDLL:
     L.sas_last_error.argtypes = [vp]
     L.sas_last_error.restype = ctypes.c_char_p
     L.sas_stage_times.argtypes = [vp, vp, ci]
+    L.sas_stage_time_means.argtypes = [vp, vp, ci, vp, ci]
     L.sas_frame_stats.argtypes = [vp, vp, ci]
     L.sas_read_projection.argtypes = [vp, vp, vp, vp, vp, vp]
     L.sas_read_tile_lists.argtypes = [vp, vp, vp, i64]

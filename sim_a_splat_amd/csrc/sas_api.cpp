@@ -57,7 +57,7 @@ struct Slot {
     unsigned *stats_host = nullptr;  // pinned, 8 words
     Scratch scr;
     SasCam cam{};
-    bool busy = false, timed = false;
+    bool busy = false, timed = false, timed_tiles = false;
     // per-frame parameter block (pinned host mirror + device copy) and the captured frame graph
     SasParams *params_host = nullptr;
     DevBuf params_dev;
@@ -102,6 +102,8 @@ struct sas_ctx {
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    double stage_sum[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t stage_frames = 0;
 };
 
 namespace {
@@ -266,10 +268,12 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
     const bool full = (a.flags & SAS_FULL_SORT) != 0;
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
-    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
+    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill,
+                               ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
     if (fill) sas_launch_depth_fill(st, tiles, P, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
@@ -318,7 +322,8 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     bool launched = false;
-    if (!timing && c->use_graphs) {
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
+    if (!timing && !ttiles && c->use_graphs) {
         Slot::GraphKey key;
         key.W = a.W; key.H = a.H;
         key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
@@ -355,6 +360,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
         HIP_TRY(c, hipGetLastError());
     }
     sl.timed = timing;
+    sl.timed_tiles = ttiles && !timing && !(a.flags & SAS_FULL_SORT);
     HIP_TRY(c, hipEventRecord(sl.done, st));
     sl.busy = true;
     c->has_frame = true;
@@ -379,6 +385,15 @@ int complete_oldest(sas_ctx *c)
         if (sl.timed) {
             for (int k = 0; k < 6; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
             (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[6]);
+            for (int k = 0; k < SAS_T_COUNT; ++k) c->stage_sum[k] += c->stage_ms[k];
+            c->stage_frames++;
+        } else if (sl.timed_tiles) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[5]) == hipSuccess) {
+                c->stage_ms[SAS_T_BLEND] = ms;
+                c->stage_sum[SAS_T_BLEND] += ms;
+                c->stage_frames++;
+            }
         }
         if (!s[2]) {
             // later work on the caller's stream is ordered after this frame
@@ -664,6 +679,19 @@ int sas_stage_times(sas_ctx *c, float *ms, int n)
 {
     if (!c || !ms) return SAS_ERR_INVALID;
     for (int k = 0; k < n && k < SAS_T_COUNT; ++k) ms[k] = c->stage_ms[k];
+    return SAS_OK;
+}
+
+int sas_stage_time_means(sas_ctx *c, float *ms, int n, int64_t *frames, int reset)
+{
+    if (!c || !ms) return SAS_ERR_INVALID;
+    for (int k = 0; k < n && k < SAS_T_COUNT; ++k)
+        ms[k] = c->stage_frames > 0 ? (float)(c->stage_sum[k] / (double)c->stage_frames) : 0.0f;
+    if (frames) *frames = c->stage_frames;
+    if (reset) {
+        for (double &v : c->stage_sum) v = 0.0;
+        c->stage_frames = 0;
+    }
     return SAS_OK;
 }
 

@@ -87,6 +87,7 @@ struct SasSortStreams {
 void sas_launch_sort(hipStream_t st, const SasScene &s, int tiles, const SasFrame &f, const SasSortStreams &ss);
 void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                       bool fast_exp, bool want_max);
+// ev_start/ev_stop (optional): stamped with the kernel's own begin/end (hipExtLaunchKernelGGL)
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                           bool fast_exp, bool want_max);
+                           bool fast_exp, bool want_max, hipEvent_t ev_start, hipEvent_t ev_stop);
 void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f);

@@ -15,6 +15,8 @@
 // Both paths composite through the same code (blend_range) and therefore produce identical bits.
 #include "sas_device.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -876,18 +878,28 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 }
 
 // Production path: lazy ordering + compositing of every tile in one launch.
+template <bool FAST, bool WMAX>
+static void launch_lazy(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *perm,
+                        int ablate, hipEvent_t e0, hipEvent_t e1)
+{
+    if (e0 && e1)
+        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm, ablate);
+    else
+        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm, ablate);
+}
+
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                           bool fast_exp, bool want_max)
+                           bool fast_exp, bool want_max, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const unsigned grid = (unsigned)tiles;
     const long long n = s.n > 0 ? s.n : 1;
     static const int ablate = getenv("SAS_ABLATE") ? atoi(getenv("SAS_ABLATE")) : 0;   // timing experiments only
     if (fast_exp) {
-        if (want_max) hipLaunchKernelGGL((k_tile_lazy<true, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
-        else hipLaunchKernelGGL((k_tile_lazy<true, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
+        if (want_max) launch_lazy<true, true>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
+        else launch_lazy<true, false>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
     } else {
-        if (want_max) hipLaunchKernelGGL((k_tile_lazy<false, true>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
-        else hipLaunchKernelGGL((k_tile_lazy<false, false>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, s.perm, ablate);
+        if (want_max) launch_lazy<false, true>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
+        else launch_lazy<false, false>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
     }
 }
 

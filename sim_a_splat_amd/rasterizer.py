@@ -132,7 +132,8 @@ class Rasterizer:
     def render(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
                background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb", "alpha", "depth"),
                depth_fill_max: bool = False, fast_exp: bool = False, timing: bool = False, block: bool = True,
-               full_sort: bool = False, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+               full_sort: bool = False, time_tiles: bool = False,
+               out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Render one view; returns device tensors ``rgb [H,W,3]``, ``alpha [H,W,1]``,
         ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``.
 
@@ -157,7 +158,7 @@ class Rasterizer:
             ptrs[k] = t.data_ptr()
         flags = (_capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0) | (_capi.SAS_FAST_EXP if fast_exp else 0) | \
                 (_capi.SAS_TIMING if timing else 0) | (0 if block else _capi.SAS_ASYNC) | \
-                (_capi.SAS_FULL_SORT if full_sort else 0)
+                (_capi.SAS_FULL_SORT if full_sort else 0) | (_capi.SAS_TIME_TILES if time_tiles else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self._L.sas_render(self._ctx, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
                                 ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
@@ -175,6 +176,14 @@ class Rasterizer:
         ms = (ctypes.c_float * len(_capi.STAGE_NAMES))()
         self._check(self._L.sas_stage_times(self._ctx, ms, len(_capi.STAGE_NAMES)), "sas_stage_times")
         return dict(zip(_capi.STAGE_NAMES, [float(x) for x in ms]))
+
+    def stage_time_means(self, reset: bool = True):
+        """(mean ms per stage, frames) over the timed frames completed since the last reset."""
+        ms = (ctypes.c_float * len(_capi.STAGE_NAMES))()
+        nf = ctypes.c_int64(0)
+        self._check(self._L.sas_stage_time_means(self._ctx, ms, len(_capi.STAGE_NAMES), ctypes.byref(nf), int(reset)),
+                    "sas_stage_time_means")
+        return dict(zip(_capi.STAGE_NAMES, [float(x) for x in ms])), int(nf.value)
 
     def stats(self) -> Dict[str, int]:
         st = (ctypes.c_int64 * len(_capi.STAT_NAMES))()
