@@ -100,6 +100,17 @@ int sas_render(sas_ctx *ctx, const float *viewmat, const float *K, int width, in
                const float *background, unsigned flags, float *rgb, float *alpha, float *depth,
                uint8_t *rgb8, void *stream);
 
+/*
+ * Render n_views views of the same size in one call.  Serves the per-camera loops of
+ * SplatHandler.render / SplatEnvWrapper.render (splat_handler.py:337-345, splat_env_wrapper.py:147-158).
+ *   viewmats [n_views,16], Ks [n_views,9] host arrays; outputs are [n_views,H,W,...] device arrays
+ *   (any may be NULL).  The views go through the two frame slots back to back (consecutive views
+ * overlap on the GPU); the call returns when all are complete unless SAS_ASYNC is given.
+ */
+int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                     const float *background, unsigned flags, float *rgb, float *alpha, float *depth,
+                     uint8_t *rgb8, void *stream);
+
 /* Complete the last SAS_ASYNC frame: synchronise, and if the intersection buffer overflowed,
  * grow it and render the frame again. */
 int sas_wait(sas_ctx *ctx);

@@ -48,3 +48,20 @@ class GSplatLoader:
         self.covs = compute_cov(self.rots, self.scales)              # :39
         self.colors = sh2rgb(f32(features_dc).reshape(-1, 3))        # :41
         self.opacities = torch.sigmoid(f32(opacity_logits)).reshape(-1, 1)   # :43-45
+
+    @classmethod
+    def from_json(cls, path, device="cpu") -> "GSplatLoader":
+        """``load_gsplat_from_json`` (splat_utils.py:51-89): keys means, rotations, colors, opacities,
+        scalings; ``colors`` are taken as given, opacities get a sigmoid, scalings an exp."""
+        from . import io
+        d = io.load_json(path)
+        self = cls.__new__(cls)
+        dev = torch.device(device)
+        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        self.device = dev
+        self.means, self.rots, self.colors = f32(d["means"]), f32(d["rotations"]), f32(d["colors"])
+        self.opacities = torch.sigmoid(f32(d["opacities"]))
+        self.scales = torch.exp(f32(d["scalings"]))
+        self.covs_inv = compute_cov(self.rots, 1.0 / self.scales)
+        self.covs = compute_cov(self.rots, self.scales)
+        return self

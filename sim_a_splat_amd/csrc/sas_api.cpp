@@ -667,6 +667,23 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     return complete_all(c);
 }
 
+int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                     const float *background, unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8,
+                     void *stream)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (n_views < 0 || (n_views > 0 && (!viewmats || !Ks))) return fail(c, SAS_ERR_INVALID, "bad view batch");
+    const size_t px = (size_t)width * (size_t)height;
+    for (int v = 0; v < n_views; ++v) {
+        int rc = sas_render(c, viewmats + 16 * v, Ks + 9 * v, width, height, background, flags | SAS_ASYNC,
+                            rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
+                            depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, stream);
+        if (rc) return rc;
+    }
+    if (flags & SAS_ASYNC) return SAS_OK;
+    return sas_wait(c);
+}
+
 int sas_wait(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;

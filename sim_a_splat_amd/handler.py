@@ -65,9 +65,16 @@ class SplatHandler:
         return poses.matrix_to_quat_wxyz(R), t
 
     def render(self, cam_poses: Sequence[Tuple[np.ndarray, np.ndarray]], render_size: Sequence[Sequence[int]]) -> List[np.ndarray]:
-        """``cam_poses``: (wxyz, position) per camera; ``render_size``: [H, W] per camera."""
-        return [self.scene.get_render(render_size[i][0], render_size[i][1], wxyz=cam_poses[i][0], position=cam_poses[i][1])
-                for i in range(len(cam_poses))]
+        """``cam_poses``: (wxyz, position) per camera; ``render_size``: [H, W] per camera.  Cameras of
+        equal size go to the GPU as one batch (the reference renders them one by one)."""
+        sizes = [(int(s[0]), int(s[1])) for s in render_size]
+        out: List[Optional[np.ndarray]] = [None] * len(cam_poses)
+        for hw in dict.fromkeys(sizes):
+            idx = [i for i, s in enumerate(sizes) if s == hw]
+            imgs = self.scene.get_renders(hw[0], hw[1], [cam_poses[i] for i in idx])
+            for j, i in enumerate(idx):
+                out[i] = imgs[j]
+        return out
 
 
 class CameraRig:

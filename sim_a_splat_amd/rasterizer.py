@@ -167,6 +167,31 @@ class Rasterizer:
         self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
+    def render_batch(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
+                     background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb",),
+                     depth_fill_max: bool = False) -> Dict[str, torch.Tensor]:
+        """Render C same-sized views in one C-ABI call: ``viewmats [C,4,4]``, ``Ks [C,3,3]`` ->
+        tensors ``[C,H,W,...]`` (the per-camera loop of the reference, splat_env_wrapper.py:147-158)."""
+        C = int(np.asarray(viewmats).shape[0]) if not isinstance(viewmats, torch.Tensor) else int(viewmats.shape[0])
+        V = self._host_f32(viewmats, 16 * C)
+        Kc = self._host_f32(Ks, 9 * C)
+        bg = self._host_f32(background, 3)
+        W, H = int(width), int(height)
+        res: Dict[str, torch.Tensor] = {}
+        ptrs = {"rgb": None, "alpha": None, "depth": None, "rgb8": None}
+        for k in want:
+            ch, dt = self._SHAPES[k]
+            res[k] = torch.empty((C, H, W, ch), dtype=dt, device=self.device)
+            ptrs[k] = res[k].data_ptr()
+        flags = _capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._L.sas_render_batch(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
+                                      ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
+        if rc != 0:
+            self._check(rc, "sas_render_batch")
+        self._keep = []
+        return res
+
     def wait(self) -> None:
         self._check(self._L.sas_wait(self._ctx), "sas_wait")
         self._keep = []

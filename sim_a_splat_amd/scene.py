@@ -120,6 +120,15 @@ class SplatScene:
         out = self._raster.render(V, K, int(width), int(height), self.background, want=("rgb8",))
         return out["rgb8"].cpu().numpy()
 
+    def get_renders(self, height: int, width: int, cam_poses, fov: Optional[float] = None) -> np.ndarray:
+        """uint8 [C,H,W,3] for C same-sized cameras ``[(wxyz, position), ...]`` in one batched call."""
+        self._sync()
+        f = self.camera.fov if fov is None else float(fov)
+        VK = [self._view_and_K(int(height), int(width), w, p, f) for (w, p) in cam_poses]
+        out = self._raster.render_batch(np.stack([v for v, _ in VK]), np.stack([k for _, k in VK]), int(width), int(height),
+                                        self.background, want=("rgb8",))
+        return out["rgb8"].cpu().numpy()
+
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
         self._sync()
         V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))

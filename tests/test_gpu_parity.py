@@ -309,3 +309,21 @@ def test_async_frames_and_stream_ordering(rasterizer):
     for i in range(len(cams)):
         assert torch.equal(snaps[i], sync[i]), i
         assert torch.equal(bufs[i]["rgb"], sync[i]), i
+
+
+def test_config4_eight_poses_uint8_batched(rasterizer):
+    """config 4 shape: the ~300k-Gaussian stand-in scene with 7 link groups, 8 ring poses at 640x480,
+    uint8 frames (Door B form), rendered as one batch; every view against the oracle."""
+    sc, cams = config_scene_and_cameras(4)
+    _upload(rasterizer, sc, group_id=sc.group_id, n_groups=7)
+    Rt = random_group_poses(7, seed=404)
+    rasterizer.set_group_poses(Rt)
+    out = rasterizer.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 640, 480, BG,
+                                  want=("rgb8", "rgb"))
+    assert out["rgb8"].shape == (8, 480, 640, 3)
+    got8, got = out["rgb8"].cpu().numpy(), out["rgb"].cpu().numpy()
+    for v in (0, 3, 7):
+        ref = oracle.render(sc.means, sc.opacities, sc.sh, cams[v].viewmat, cams[v].K, 640, 480, quats=sc.quats,
+                            scales=sc.scales, sh_degree=3, group_id=sc.group_id, group_Rt=Rt, background=BG, want_rgb8=True)
+        assert np.abs(got[v] - ref["rgb"]).max() <= TOL
+        assert np.array_equal(got8[v], ref["rgb8"]) and np.array_equal(got[v], ref["rgb"])
