@@ -13,6 +13,14 @@ constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
 
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// 16-byte non-temporal (streaming) load
+DEV float4 nt_load(const float4 *p)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---- contract transcendental functions (mirror sas_oracle_expf / sas_oracle_logf) -------------
 DEV float c_expf(float x)
 {

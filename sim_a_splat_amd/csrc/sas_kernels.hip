@@ -181,9 +181,11 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__
     bool vis = false;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     if (in_range) {
-        const float4 a0 = s.g0[i];
-        const float4 a1 = s.g1[i];
-        const float4 a2 = s.g2[i];
+        // the scene is streamed once per frame: non-temporal loads keep it from evicting the
+        // records / keys that the tile kernels (of this and the other in-flight frame) re-read
+        const float4 a0 = nt_load(s.g0 + i);
+        const float4 a1 = nt_load(s.g1 + i);
+        const float4 a2 = nt_load(s.g2 + i);
         float m[3] = {a0.x, a0.y, a0.z};
         const float op = a0.w;
         const float *G = nullptr;
@@ -300,12 +302,12 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__
                         float sh[PL * 4];
 #pragma unroll
                         for (int p = 0; p < PL; ++p) {
-                            const float4 v = s.col[(int64_t)p * s.n_pad + i];
+                            const float4 v = nt_load(s.col + (int64_t)p * s.n_pad + i);
                             sh[4 * p] = v.x; sh[4 * p + 1] = v.y; sh[4 * p + 2] = v.z; sh[4 * p + 3] = v.w;
                         }
                         sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
                     } else {
-                        const float4 v = s.col[i];
+                        const float4 v = nt_load(s.col + i);
                         rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
                     }
                     // conservative skip threshold for the blend stage: alpha >= 1/255 implies
