@@ -34,12 +34,12 @@ from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, make_scene, ri
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(n, n_vis, m, w, h, out_bytes_per_pixel=12):
+def algorithmic_bytes(n, n_vis, m, w, h, out_bytes_per_pixel=15):
     """N*236 + N_vis*44 + M*60 + W*H*out."""
     return n * 236 + n_vis * 44 + m * 60 + w * h * out_bytes_per_pixel
 
 
-def tile_kernel_bytes(m, w, h, out_bytes_per_pixel=12):
+def tile_kernel_bytes(m, w, h, out_bytes_per_pixel=15):
     """Dominant kernel (k_tile_lazy = per-tile ordering + compositing), SURVEY.md 8d terms:
     8 B key read per intersection + 44 B gather per intersection (id 4 + record 40) + the frame."""
     return m * (8 + 44) + w * h * out_bytes_per_pixel
@@ -96,23 +96,27 @@ def main():
     cam = ring_camera(W, H, 1000.0, yaw_deg=45.0 * rank)   # one independent view per GPU
     r = Rasterizer(dev)
     r.upload(scene.means, scene.opacities, scene.sh, quats=scene.quats, scales=scene.scales, sh_degree=3)
-    bufs = [{"rgb": torch.empty((H, W, 3), dtype=torch.float32, device=dev)} for _ in range(3)]
+    # every rank writes the float32 frame (the metric's output) and its uint8 twin; the gather moves
+    # the uint8 frame, the format Gym observations are exchanged in (splat_env_wrapper.py:135-137):
+    # 6.2 MB instead of 24.9 MB per frame keeps the xGMI transfer shorter than a frame
+    bufs = [{"rgb": torch.empty((H, W, 3), dtype=torch.float32, device=dev),
+             "rgb8": torch.empty((H, W, 3), dtype=torch.uint8, device=dev)} for _ in range(3)]
     gather = sdist.FrameGather(world, rank)
 
     def step(i, timing):
         out = bufs[i % 3]
-        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=out, block=False,
+        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=out, block=False,
                  time_tiles=timing)
         # After render(i) returns, the current stream is ordered behind frame i-1 (C ABI contract):
         # gather that one, so the xGMI transfer of frame i-1 overlaps the rendering of frame i.
         if world > 1 and i > 0:
-            gather.start(bufs[(i - 1) % 3]["rgb"])
+            gather.start(bufs[(i - 1) % 3]["rgb8"])
 
     def sync(last_i):
         r.wait()                       # orders the current stream behind every frame
         if world > 1:
             if last_i >= 0:
-                gather.start(bufs[last_i % 3]["rgb"])
+                gather.start(bufs[last_i % 3]["rgb8"])
             gather.finish()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -139,7 +143,7 @@ def main():
     # every stage boundary, after the timed region
     stage = {}
     for i in range(10):
-        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=bufs[0], timing=True)
+        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=bufs[0], timing=True)
         for k, v in r.stage_times().items():
             stage.setdefault(k, []).append(v)
     blend_s = tile_ms * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
@@ -155,9 +159,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: 1M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, "
-                                   "fx=fy=1000, one view per GPU, float32 RGB out",
+                                   "fx=fy=1000, one view per GPU, float32 RGB + uint8 RGB out",
                        "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
-                       "views_per_step": world, "parallelism": f"views{world}"},
+                       "views_per_step": world, "parallelism": f"views{world}",
+                       "gather": "uint8 frames to rank 0 (RCCL), one frame behind the renderer" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy"),
                          "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames,
