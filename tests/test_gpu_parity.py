@@ -327,3 +327,49 @@ def test_config4_eight_poses_uint8_batched(rasterizer):
                             scales=sc.scales, sh_degree=3, group_id=sc.group_id, group_Rt=Rt, background=BG, want_rgb8=True)
         assert np.abs(got[v] - ref["rgb"]).max() <= TOL
         assert np.array_equal(got8[v], ref["rgb8"]) and np.array_equal(got[v], ref["rgb"])
+
+
+def test_c_abi_error_paths_and_timing_means():
+    """Status codes instead of exceptions across the ABI; the wrapper raises RuntimeError (SasError)."""
+    import ctypes
+    import torch
+    from sim_a_splat_amd import _capi
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    L = _capi.lib()
+    ctx = ctypes.c_void_p()
+    assert L.sas_create(9999, ctypes.byref(ctx)) == -1 and not ctx.value            # SAS_ERR_INVALID
+    r = Rasterizer(0)
+    cam = ring_camera(64, 48, 60.0)
+    with pytest.raises(_capi.SasError, match="sas_scene_upload"):
+        r.render(cam.viewmat, cam.K, 64, 48)                                         # SAS_ERR_NO_SCENE
+    sc = make_scene(500, seed=7, log_scale_mean=float(np.log(0.05)))
+    with pytest.raises(_capi.SasError, match="sh_degree"):
+        r.upload(sc.means, sc.opacities, np.zeros((500, 25, 3), np.float32), quats=sc.quats, scales=sc.scales, sh_degree=4)
+    with pytest.raises(_capi.SasError, match="group_id"):
+        r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, group_id=np.full(500, 9, np.uint8), n_groups=3)
+    _upload(r, sc)
+    with pytest.raises(_capi.SasError, match="image size"):
+        r.render(cam.viewmat, cam.K, 0, 48)
+    bad_K = cam.K.copy()
+    bad_K[0, 0] = -1.0
+    with pytest.raises(_capi.SasError, match="focal"):
+        r.render(cam.viewmat, bad_K, 64, 48)
+    with pytest.raises(_capi.SasError, match="groups"):
+        r.set_group_poses(np.zeros((2, 12), np.float32))                             # scene has no groups
+    with pytest.raises(ValueError):
+        r.render(cam.viewmat, cam.K, 64, 48, out={"rgb": torch.empty((48, 64, 3), device="cuda:0", dtype=torch.float16)})
+    # the context is still usable after every failure
+    a = r.render(cam.viewmat, cam.K, 64, 48, BG, want=("rgb",))["rgb"].cpu().numpy()
+    ref = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, 64, 48, quats=sc.quats, scales=sc.scales, background=BG)
+    assert np.array_equal(a, ref["rgb"])
+    # timing: per-stage events of an isolated frame, and the pipelined tile-kernel timing means
+    r.render(cam.viewmat, cam.K, 64, 48, BG, want=("rgb",), timing=True)
+    st = r.stage_times()
+    assert st["total"] > 0 and st["project"] > 0 and st["blend"] > 0
+    r.stage_time_means(reset=True)
+    for _ in range(5):
+        r.render(cam.viewmat, cam.K, 64, 48, BG, want=("rgb",), block=False, time_tiles=True)
+    r.wait()
+    means, frames = r.stage_time_means(reset=True)
+    assert frames == 5 and 0 < means["blend"] < 5.0
+    r.close()
