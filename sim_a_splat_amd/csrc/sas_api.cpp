@@ -84,7 +84,7 @@ struct sas_ctx {
     int device = 0;
     std::string err;
     // scene
-    DevBuf g0, g1, g2, col, groups, perm, inv_perm;
+    DevBuf g0, g1, g2, col, groups, perm;
     std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
@@ -492,7 +492,7 @@ int sas_destroy(sas_ctx *c)
                           &sl.scr.wgvis, &sl.scr.tilemax})
             release(*b);
     }
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->inv_perm}) release(*b);
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm}) release(*b);
     delete c;
     return SAS_OK;
 }
@@ -531,7 +531,6 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
 
     c->perm_host.clear();
     if ((rc = ensure(c, c->perm, sizeof(int) * np))) return rc;
-    if ((rc = ensure(c, c->inv_perm, sizeof(int) * np))) return rc;
     if (n > 0) {
         // storage order from host copies of the means / group ids
         std::vector<float> h_means((size_t)3 * n);
@@ -544,10 +543,7 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
                 if (h_gid[(size_t)i] >= n_groups) return fail(c, SAS_ERR_INVALID, "group_id[%lld]=%d >= n_groups=%d", (long long)i, (int)h_gid[(size_t)i], n_groups);
         }
         storage_order(n, h_means.data(), group_id ? h_gid.data() : nullptr, c->perm_host);
-        std::vector<int> inv((size_t)n);
-        for (int64_t j = 0; j < n; ++j) inv[(size_t)c->perm_host[(size_t)j]] = (int)j;
         HIP_TRY(c, hipMemcpy(c->perm.p, c->perm_host.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->inv_perm.p, inv.data(), sizeof(int) * n, hipMemcpyHostToDevice));
 
         // stage the caller's arrays (host or device) and re-lay them out on the device
         DevBuf s_means, s_q, s_s, s_cov, s_op, s_col, s_gid;
@@ -583,7 +579,6 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     c->scene.g2 = (const float4 *)c->g2.p;
     c->scene.col = (const float4 *)c->col.p;
     c->scene.perm = (const int *)c->perm.p;
-    c->scene.inv_perm = (const int *)c->inv_perm.p;
     c->scene.n = n;
     c->scene.n_pad = n_pad;
     c->scene.sh_degree = deg;

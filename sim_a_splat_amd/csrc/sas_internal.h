@@ -27,7 +27,6 @@ struct SasScene {
     const float4 *g0, *g1, *g2, *col;
     const float *group_Rt;  // [n_groups,12] or nullptr
     const int *perm;        // [n] slot j holds the caller's Gaussian perm[j] (Hilbert order, by group)
-    const int *inv_perm;    // [n] caller index -> slot
     int64_t n;
     int64_t n_pad;     // plane stride
     int sh_degree;     // -1: col plane 0 holds final rgb

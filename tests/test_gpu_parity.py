@@ -373,3 +373,64 @@ def test_c_abi_error_paths_and_timing_means():
     means, frames = r.stage_time_means(reset=True)
     assert frames == 5 and 0 < means["blend"] < 5.0
     r.close()
+
+
+def _rand_rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_edge_cases(rasterizer, seed):
+    """Random cameras (also INSIDE the scene: near-plane culls, clamped Jacobian limits), odd image
+    sizes, off-centre principal points, non-square pixels, extreme anisotropy, screen-filling
+    splats, SH degree 0..3 or covariance + RGB input with group poses."""
+    from sim_a_splat_amd.synthetic import Camera
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6000))
+    sc = make_scene(n, seed=2000 + seed, log_scale_mean=float(np.log(rng.choice([0.005, 0.03, 0.15]))))
+    sc.scales[:] = (sc.scales * np.exp(rng.normal(0, 1.0, size=sc.scales.shape))).astype(np.float32)   # anisotropy
+    if n > 10:
+        sc.scales[: max(1, n // 200)] *= 20.0                                                           # huge splats
+    W, H = [(1, 1), (15, 17), (16, 16), (33, 7), (100, 100), (257, 129), (640, 360)][seed % 7]
+    fx = float(rng.uniform(0.3, 2.0) * W + 5)
+    fy = float(fx * rng.uniform(0.8, 1.25))
+    K = np.array([[fx, 0, W * rng.uniform(0.2, 0.8)], [0, fy, H * rng.uniform(0.2, 0.8)], [0, 0, 1]], np.float32)
+    R = _rand_rot(rng)
+    eye = rng.uniform(-1, 1, size=3) * (0.5 if seed % 2 else 3.0)        # odd seeds: camera inside the cloud
+    V = np.eye(4)
+    V[:3, :3] = R
+    V[:3, 3] = -R @ eye
+    cam = Camera(V.astype(np.float32), K, W, H)
+    deg = seed % 5 - 1
+    gid = Rt = None
+    if deg < 0:                                                          # Door-B form
+        from oracle import ref_math
+        q = sc.quats / np.linalg.norm(sc.quats, axis=1, keepdims=True)
+        Rm = np.stack([ref_math.quat_wxyz_to_R(x) for x in q]).astype(np.float32)
+        M = Rm * sc.scales[:, None, :]
+        cov = (M @ M.transpose(0, 2, 1)).astype(np.float32)
+        cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+        rgb = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
+        gid = rng.integers(0, 5, size=n).astype(np.uint8)
+        Rt = random_group_poses(5, seed=seed)
+        rasterizer.upload(sc.means, sc.opacities, rgb, covariances=cov, sh_degree=-1, group_id=gid, n_groups=5)
+        rasterizer.set_group_poses(Rt)
+        ref = oracle.render(sc.means, sc.opacities, rgb, cam.viewmat, K, W, H, cov6=cov6, sh_degree=-1, group_id=gid,
+                            group_Rt=Rt, background=BG, want_rgb8=True, depth_mode=1)
+    else:
+        sh = np.ascontiguousarray(sc.sh[:, : (deg + 1) ** 2])
+        rasterizer.upload(sc.means, sc.opacities, sh, quats=sc.quats, scales=sc.scales, sh_degree=deg)
+        ref = oracle.render(sc.means, sc.opacities, sh, cam.viewmat, K, W, H, quats=sc.quats, scales=sc.scales,
+                            sh_degree=deg, background=BG, want_rgb8=True, depth_mode=1)
+    out = rasterizer.render(cam.viewmat, K, W, H, BG, want=("rgb", "alpha", "depth", "rgb8"), depth_fill_max=True)
+    st = rasterizer.stats()
+    assert st["n_visible"] == ref["n_visible"] and st["n_isect"] == ref["n_isect"]
+    for k in ("rgb", "alpha", "depth", "rgb8"):
+        got = out[k].cpu().numpy()
+        assert np.abs(got.astype(np.float64) - ref[k]).max() <= (1 if k == "rgb8" else 1e-4), k
+        assert np.array_equal(got, ref[k]), k
