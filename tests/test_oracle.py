@@ -134,3 +134,15 @@ def test_ref_math_compute_cov_matches_reference_fixture(golden_dir):
 def test_sh2rgb_constant():
     assert ref_math.C0 == 0.28209479177387814
     np.testing.assert_allclose(ref_math.sh2rgb(np.array([0.0, 1.0, -1.0])), [0.5, 0.78209479, 0.21790521], atol=1e-8)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """CPU-only sanitizer leg: the oracle's allocations and indexing on ragged / empty / grouped scenes."""
+    import subprocess
+    from pathlib import Path
+    odir = Path(__file__).resolve().parent.parent / "oracle"
+    subprocess.run(["make", "-C", str(odir), "-s", "asan"], check=True)
+    res = subprocess.run([str(odir / "_build" / "oracle_asan")], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr
+    assert res.stdout.count("intersections") == 5
