@@ -1,16 +1,16 @@
-// sas_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the render-image hot path.
+// sas_kernels.hip -- projection and binning kernels of the render-image hot path, hand-written for
+// gfx950 (CDNA4, wave64).  The per-tile stages (depth ordering, compositing) are in sas_tile.hip.
 //
 // Stage map (the algorithm is gsplat 1.5.2's, the decomposition is not):
-//   k_project   T1+T2  one lane per Gaussian: 16-byte plane loads, EWA projection, SH colour,
-//                      48-byte projected record, tile rectangle, per-tile counts
-//   k_scan      T5     exclusive scan of the per-tile counts (tile_offset, scatter cursors)
-//   k_scatter   T3     (depth bits | index) keys into per-tile segments
-//   k_sort      T4     per-tile stable LSD radix sort on depth bits in LDS, wave-ballot ranks
-//                      (replaces the global 64-bit radix sort)
-//   k_blend     T6+T0  one workgroup per 16x16 tile (longest list first), one wave per 8x8
-//                      quadrant, LDS-staged splat queue compacted per wave by ballot from the
-//                      quadrant hit masks, front-to-back compositing,
-//                      background / clamp / uint8 / expected-depth epilogue
+//   k_relayout  upload  caller's AoS arrays -> Hilbert-ordered 16-byte planes (once per scene)
+//   k_project   T1+T2   one lane per Gaussian: non-temporal 16-byte plane loads, EWA projection,
+//                       SH colour, 48-byte projected record, tile rectangle; per-tile counts through
+//                       an LDS histogram over the workgroup's tile window (one global atomic per
+//                       touched tile)
+//   k_scan      T5      workgroup 0: exclusive scan of the counts (tile_offset, scatter cursors),
+//                       visible count; workgroup 1: tiles ordered by list length, sort classes
+//   k_scatter   T3      (depth bits | storage slot) keys into per-tile segments, runs reserved per
+//                       (workgroup, tile) with one returning atomic
 //
 // ARITHMETIC CONTRACT: every value that reaches an output is produced by the same
 // sequence of IEEE binary32 operations as oracle/sas_oracle.c -- explicit __builtin_fmaf where
