@@ -101,6 +101,18 @@ int sas_render(sas_ctx *ctx, const float *viewmat, const float *K, int width, in
                uint8_t *rgb8, void *stream);
 
 /*
+ * sas_render with the RGB-D consumer fused into the depth pass.  Replaces the unprojection of
+ * GaussianSplat.generate_RGBD_point_cloud (ns_utils/nerfstudio_utils.py:424-445):
+ *   points [H,W,3]  camera-frame (x, y, z) = ((u - cx) * d / fx, (v - cy) * d / fy, d), d = the depth output
+ *                   (after the SAS_DEPTH_FILL_MAX fill when that flag is set); u, v integer pixel indices
+ *   mask   [H,W]    uint8: d < *max_depth, or all ones when max_depth is NULL
+ * `depth` is required when points or mask is given; points / mask may each be NULL.
+ */
+int sas_render_rgbd(sas_ctx *ctx, const float viewmat[16], const float K[9], int width, int height,
+                    const float background[3], unsigned flags, const float *max_depth, float *rgb, float *alpha,
+                    float *depth, float *points, uint8_t *mask, void *stream);
+
+/*
  * Render n_views views of the same size in one call.  Serves the per-camera loops of
  * SplatHandler.render / SplatEnvWrapper.render (splat_handler.py:337-345, splat_env_wrapper.py:147-158).
  *   viewmats [n_views,16], Ks [n_views,9] host arrays; outputs are [n_views,H,W,...] device arrays

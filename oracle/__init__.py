@@ -62,6 +62,9 @@ def lib():
         _lib.sas_oracle_render.restype = ctypes.c_int
         _lib.sas_oracle_render.argtypes = [ctypes.POINTER(_Scene)] + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + \
             [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int64, ctypes.c_void_p]
+        _lib.sas_oracle_unproject.restype = None
+        _lib.sas_oracle_unproject.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
+            [ctypes.c_void_p] * 3
         _lib.sas_oracle_num_threads.restype = ctypes.c_int
         _lib.sas_oracle_set_num_threads.argtypes = [ctypes.c_int]
     return _lib
@@ -157,6 +160,18 @@ def render(means, opacities, colors, viewmat, K, width: int, height: int, *, qua
         out.update(radii=radii, means2d=means2d, depths=depths, conics=conics, colors=cols,
                    tile_offsets=toff, sorted_ids=sids[:cap])
     return out
+
+
+def unproject(depth, K, max_depth=1.0):
+    """Camera-frame points [H,W,3] and mask [H,W] of a depth image (nerfstudio_utils.py:424-445)."""
+    d = _f32(np.asarray(depth).reshape(np.asarray(depth).shape[0], -1))
+    H, W = d.shape
+    Kc = _f32(K, (3, 3))
+    pts = np.zeros((H, W, 3), np.float32)
+    mask = np.zeros((H, W), np.uint8)
+    md = ctypes.c_float(max_depth) if max_depth is not None else None
+    lib().sas_oracle_unproject(_ptr(d), _ptr(Kc), W, H, ctypes.byref(md) if md is not None else None, _ptr(pts), _ptr(mask))
+    return pts, mask.astype(bool)
 
 
 def render_scene(scene, cam, **kw) -> Dict[str, np.ndarray]:

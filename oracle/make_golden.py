@@ -7,6 +7,10 @@
     torch-only module).  Only data is stored, no reference source.
 (2) render_twin_*.npz -- tiny seeded scenes rendered by the float64 NumPy twin; they pin the
     C oracle (tests/test_oracle.py) and, through it, the HIP kernels.
+(3) scene_assets_xarm6_1.npz -- the small data files the reference ships for its real scene
+    (robots-scene-v2 / xarm6-1): ICP similarity, mask-time joint configuration, dataparser
+    transform and the seven per-link masks, bit-packed.  Data only; the masks' pickled .npy is
+    read with the whitelisting unpickler of sim_a_splat_amd.io, never np.load(allow_pickle=True).
 The reference tree does not exist on the GPU box; tests read only the committed fixtures.
 """
 from __future__ import annotations
@@ -77,10 +81,31 @@ def gen_twin_renders():
         print(name, out["n_visible"], out["n_isect"])
 
 
+ASSETS = Path("/root/reference/assets/robots-scene-v2")
+
+
+def gen_scene_assets():
+    from sim_a_splat_amd import io
+    d = ASSETS / "masks" / "xarm6-1"
+    masks = io.load_link_masks(d / "link_masks_global_dict.npy")
+    icp = io.load_icp_transformation(d / "icp_transformation.npy")
+    jc = io.load_joint_config(d / "joint_config.npy")
+    T, scale = io.load_dataparser_transforms(next((ASSETS / "splatfacto").glob("*/dataparser_transforms.json")))
+    names = sorted(masks, key=lambda k: int(k[4:]))
+    n = len(masks[names[0]])
+    np.savez_compressed(GOLD / "scene_assets_xarm6_1.npz", icp_transformation=icp, joint_config=jc,
+                        dataparser_transform=T, dataparser_scale=np.float64(scale), n=np.int64(n),
+                        link_names=np.array(names), mask_bits=np.stack([np.packbits(masks[k]) for k in names]),
+                        mask_counts=np.array([int(masks[k].sum()) for k in names], np.int64))
+    print("scene_assets_xarm6_1.npz", n, [int(masks[k].sum()) for k in names])
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     if REF.exists():
         gen_compute_cov()
     else:
         print("reference tree absent: compute_cov.npz not regenerated")
+    if ASSETS.exists():
+        gen_scene_assets()
     gen_twin_renders()

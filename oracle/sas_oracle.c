@@ -512,6 +512,26 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
     return 0;
 }
 
+/* RGB-D consumer, nerfstudio_utils.py:424-445: x = (u - cx) * d / fx, y = (v - cy) * d / fy, z = d
+ * with integer pixel indices u, v (torch.arange), mask = d < max_depth (all ones when max_depth is
+ * NULL).  The reference evaluates it in float32 in exactly this order. */
+void sas_oracle_unproject(const float *depth, const float K[9], int W, int H, const float *max_depth, float *points,
+                          uint8_t *mask)
+{
+    const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            const int64_t p = (int64_t)v * W + u;
+            const float d = depth[p];
+            if (points) {
+                points[3 * p] = ((float)u - cx) * d / fx;
+                points[3 * p + 1] = ((float)v - cy) * d / fy;
+                points[3 * p + 2] = d;
+            }
+            if (mask) mask[p] = max_depth ? (d < *max_depth ? 1 : 0) : 1;
+        }
+}
+
 int sas_oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -30,6 +30,10 @@ struct RenderArgs {
     unsigned flags = 0;
     float *rgb = nullptr, *alpha = nullptr, *depth = nullptr;
     uint8_t *rgb8 = nullptr;
+    float *points = nullptr;   // RGB-D tail (sas_render_rgbd)
+    uint8_t *mask = nullptr;
+    float max_depth = 0.0f;
+    bool use_max_depth = false;
     hipStream_t stream = nullptr;
     bool valid = false;
 };
@@ -275,7 +279,8 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
     else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill,
                                ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
-    if (fill) sas_launch_depth_fill(st, tiles, P, f);
+    const bool pts = a.depth && (a.points || a.mask);
+    if (fill || pts) sas_launch_depth_tail(st, tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return SAS_OK;
@@ -315,6 +320,8 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     hp.cam = cam;
     hp.out.rgb = a.rgb; hp.out.alpha = a.alpha; hp.out.depth = a.depth; hp.out.rgb8 = a.rgb8;
     hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
+    hp.out.points = a.points; hp.out.mask = a.mask;
+    hp.out.max_depth = a.max_depth; hp.out.use_max_depth = a.use_max_depth ? 1 : 0;
 
     hipStream_t st = sl.fs;
     const bool timing = (a.flags & SAS_TIMING) != 0;
@@ -328,6 +335,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
         key.W = a.W; key.H = a.H;
         key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
         if (!a.depth) key.flags &= ~SAS_DEPTH_FILL_MAX;
+        if (a.depth && (a.points || a.mask)) key.flags |= 1u << 31;   // the tail also unprojects
         key.n = n; key.cap = q.cap; key.scene_version = c->scene_version;
         key.keys = q.keys.p; key.rec = q.rec.p; key.tilebuf = q.tilebuf.p; key.counters = q.counters.p;
         if (!sl.gexec || !(key == sl.gkey)) {
@@ -617,8 +625,9 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
     return SAS_OK;
 }
 
-int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
-               unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, void *stream)
+static int render_impl(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
+                       unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, float *points,
+                       uint8_t *mask, const float *max_depth, void *stream)
 {
     if (!c) return SAS_ERR_INVALID;
     if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "sas_render before sas_scene_upload");
@@ -626,6 +635,7 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     if (width <= 0 || height <= 0 || width > 65535 * SAS_TILE || height > 65535 * SAS_TILE)
         return fail(c, SAS_ERR_INVALID, "bad image size %dx%d", width, height);
     if (!(K[0] > 0.0f) || !(K[4] > 0.0f)) return fail(c, SAS_ERR_INVALID, "focal lengths must be positive");
+    if ((points || mask) && !depth) return fail(c, SAS_ERR_INVALID, "points / mask need the depth output");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->inflight > 0 && (st != c->stream || (flags & SAS_TIMING))) {
@@ -645,6 +655,9 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
     a.W = width; a.H = height; a.flags = flags;
     a.rgb = rgb; a.alpha = alpha; a.depth = depth; a.rgb8 = rgb8;
+    a.points = points; a.mask = mask;
+    a.use_max_depth = max_depth != nullptr;
+    a.max_depth = max_depth ? *max_depth : 0.0f;
     a.stream = st;
     a.valid = true;
     int rc = enqueue_frame(c, sl);
@@ -660,6 +673,21 @@ int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int 
     c->last_slot = si;
     if (flags & SAS_ASYNC) return SAS_OK;
     return complete_all(c);
+}
+
+int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
+               unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, void *stream)
+{
+    return render_impl(c, viewmat, K, width, height, background, flags, rgb, alpha, depth, rgb8, nullptr, nullptr,
+                       nullptr, stream);
+}
+
+int sas_render_rgbd(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
+                    unsigned flags, const float *max_depth, float *rgb, float *alpha, float *depth, float *points,
+                    uint8_t *mask, void *stream)
+{
+    return render_impl(c, viewmat, K, width, height, background, flags, rgb, alpha, depth, nullptr, points, mask,
+                       max_depth, stream);
 }
 
 int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,

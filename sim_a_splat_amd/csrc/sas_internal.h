@@ -62,6 +62,11 @@ struct SasOutputs {
     float *rgb, *alpha, *depth;
     uint8_t *rgb8;
     float bg[3];
+    // RGB-D tail (sas_render_rgbd): camera-frame points [H,W,3] and depth mask [H,W], or nullptr
+    float *points;
+    uint8_t *mask;
+    float max_depth;      // mask = depth < max_depth when use_max_depth, else all ones
+    int use_max_depth;
 };
 
 // Per-frame parameters, resident in device memory (one block per frame slot) so that a captured
@@ -89,4 +94,5 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 // ev_start/ev_stop (optional): stamped with the kernel's own begin/end (hipExtLaunchKernelGGL)
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                            bool fast_exp, bool want_max, hipEvent_t ev_start, hipEvent_t ev_stop);
-void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f);
+// depth tail: fill depth where nothing was composited (fill) and/or unproject it (points)
+void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f, bool fill, bool points);

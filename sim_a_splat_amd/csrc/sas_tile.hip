@@ -544,7 +544,7 @@ DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int i
     return ED;
 }
 
-// per-tile max of the expected depth (reduced over tiles by k_depth_fill); all threads call it
+// per-tile max of the expected depth (reduced over tiles by k_depth_tail); all threads call it
 DEV void store_tile_max(const SasFrame &f, int tile, float ED, unsigned *s_wmax)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -798,23 +798,48 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
     if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
 }
 
-// depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
-// Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
-// no same-address atomics.  ED >= 0, so the float order is the order of the bit patterns.
-__global__ __launch_bounds__(256) void k_depth_fill(const unsigned *tile_max, int tiles, const SasParams *__restrict__ P)
+// Depth tail, one pass over the depth image after the tile kernel.
+// FILL: depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
+//   Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
+//   no same-address atomics.  ED >= 0, so the float order is the order of the bit patterns.
+// PTS: the RGB-D consumer of nerfstudio_utils.py:424-445 fused into the same pass:
+//   x = (u - cx) * d / fx, y = (v - cy) * d / fy, z = d;  mask = d < max_depth.
+template <bool FILL, bool PTS>
+__global__ __launch_bounds__(256) void k_depth_tail(const unsigned *tile_max, int tiles, const SasParams *__restrict__ P)
 {
     __shared__ unsigned s_max[4];
-    float *depth = P->out.depth;
-    const long long npix = (long long)P->cam.W * P->cam.H;
-    unsigned m = 0;
-    for (int t = threadIdx.x; t < tiles; t += 256) m = max(m, tile_max[t]);
+    const SasOutputs o = P->out;
+    float *depth = o.depth;
+    const int W = P->cam.W;
+    const long long npix = (long long)W * P->cam.H;
+    float mx = 0.0f;
+    if (FILL) {
+        unsigned m = 0;
+        for (int t = threadIdx.x; t < tiles; t += 256) m = max(m, tile_max[t]);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
-    __syncthreads();
-    const float mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
-        if (depth[p] == 0.0f) depth[p] = mx;
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+    }
+    const float fx = P->cam.fx, fy = P->cam.fy, cx = P->cam.cx, cy = P->cam.cy;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        float d = depth[p];
+        if (FILL && d == 0.0f) {
+            d = mx;
+            depth[p] = d;
+        }
+        if (PTS) {
+            const int v = (int)(p / W), u = (int)(p - (long long)v * W);
+            if (o.points) {
+                float *q = o.points + 3 * p;
+                q[0] = ((float)u - cx) * d / fx;
+                q[1] = ((float)v - cy) * d / fy;
+                q[2] = d;
+            }
+            if (o.mask) o.mask[p] = o.use_max_depth ? (d < o.max_depth ? 1 : 0) : 1;
+        }
+    }
 }
 
 }  // namespace
@@ -903,7 +928,10 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
     }
 }
 
-void sas_launch_depth_fill(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f)
+void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f, bool fill, bool points)
 {
-    hipLaunchKernelGGL(k_depth_fill, dim3(1024), dim3(256), 0, st, (const unsigned *)f.tile_max, tiles, P);
+    const unsigned *tm = (const unsigned *)f.tile_max;
+    if (fill && points) hipLaunchKernelGGL((k_depth_tail<true, true>), dim3(1024), dim3(256), 0, st, tm, tiles, P);
+    else if (fill) hipLaunchKernelGGL((k_depth_tail<true, false>), dim3(1024), dim3(256), 0, st, tm, tiles, P);
+    else if (points) hipLaunchKernelGGL((k_depth_tail<false, true>), dim3(1024), dim3(256), 0, st, tm, tiles, P);
 }

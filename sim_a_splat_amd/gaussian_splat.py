@@ -126,13 +126,14 @@ class GaussianSplat:
         return outputs
 
     def generate_RGBD_point_cloud(self, pose, max_depth: Optional[float] = 1.0):
-        """Depth unprojection of nerfstudio_utils.py:375-472 (tensor results only)."""
-        outputs = self.render(pose)
-        cam_depth = outputs["depth"].squeeze()
-        cam_rgb = outputs["rgb"]
-        depth_mask = torch.ones_like(cam_depth, dtype=torch.bool) if max_depth is None else cam_depth < max_depth
+        """RGB-D consumer of nerfstudio_utils.py:375-472 (tensor results only; the open3d cloud is
+        ``points[mask]`` / ``rgb[mask]``).  Render and unprojection are one C-ABI call: the depth
+        tail kernel writes the camera-frame points and the depth mask."""
+        c2w = torch.as_tensor(pose, dtype=torch.float32)[:3, ...]
+        V = viewmat_from_c2w_opengl(c2w)
         H, W, K = self.get_camera_intrinsics()
-        K = K.to(cam_depth.device)
-        U, Vg = torch.meshgrid(torch.arange(W, device=cam_depth.device), torch.arange(H, device=cam_depth.device), indexing="xy")
-        pts = torch.stack(((U - K[0, 2]) * cam_depth / K[0, 0], (Vg - K[1, 2]) * cam_depth / K[1, 1], cam_depth), dim=-1)
-        return cam_rgb, pts, None, depth_mask, outputs
+        bg = self.model.background_color
+        out = self.model._rasterizer().render_rgbd(V, K.numpy(), W, H, bg.tolist(), max_depth=max_depth)
+        outputs = {"rgb": out["rgb"], "depth": out["depth"], "accumulation": out["alpha"],
+                   "background": bg.to(self.device).expand(H, W, 3)}
+        return out["rgb"], out["points"], None, out["mask"], outputs

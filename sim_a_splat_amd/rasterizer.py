@@ -167,6 +167,33 @@ class Rasterizer:
         self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
+    def render_rgbd(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
+                    background: Sequence[float] = (0.0, 0.0, 0.0), *, max_depth: Optional[float] = 1.0,
+                    depth_fill_max: bool = True) -> Dict[str, torch.Tensor]:
+        """Render with the RGB-D consumer fused into the depth pass (sas_render_rgbd): besides
+        ``rgb``/``alpha``/``depth`` returns ``points [H,W,3]`` (camera frame) and ``mask [H,W]``
+        (bool, ``depth < max_depth``; all true for ``max_depth=None``) -- nerfstudio_utils.py:424-445."""
+        V = self._host_f32(viewmat, 16)
+        Kc = self._host_f32(K, 9)
+        bg = self._host_f32(background, 3)
+        W, H = int(width), int(height)
+        res = {k: torch.empty((H, W, ch), dtype=dt, device=self.device)
+               for k, (ch, dt) in self._SHAPES.items() if k != "rgb8"}
+        res["points"] = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+        mask8 = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        md = ctypes.c_float(max_depth) if max_depth is not None else None
+        flags = _capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._L.sas_render_rgbd(self._ctx, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
+                                     ctypes.addressof(md) if md is not None else None,
+                                     res["rgb"].data_ptr(), res["alpha"].data_ptr(), res["depth"].data_ptr(),
+                                     res["points"].data_ptr(), mask8.data_ptr(), stream)
+        if rc != 0:
+            self._check(rc, "sas_render_rgbd")
+        self._keep = []
+        res["mask"] = mask8.view(torch.bool)
+        return res
+
     def render_batch(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
                      background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb",),
                      depth_fill_max: bool = False) -> Dict[str, torch.Tensor]:

@@ -43,8 +43,44 @@ def test_door_a_gaussian_splat_render():
     rgb, pts, _, mask, _ = gs.generate_RGBD_point_cloud(pose, max_depth=3.0)
     d = out["depth"].squeeze()
     assert pts.shape == (150, 200, 3) and torch.equal(pts[..., 2], d) and torch.equal(mask, d < 3.0)
-    u = torch.arange(200, device=d.device)[None, :].expand(150, 200)
-    assert torch.allclose(pts[..., 0], (u - K[0, 2]) * d / K[0, 0])
+    # fused depth tail against the oracle's unprojection of the oracle's depth: bit-exact
+    opts, omask = oracle.unproject(ref["depth"], K, max_depth=3.0)
+    assert np.array_equal(pts.cpu().numpy(), opts) and np.array_equal(mask.cpu().numpy(), omask)
+    assert 0 < omask.sum() < omask.size
+    assert torch.equal(rgb, out["rgb"])
+    _, pts2, _, mask2, _ = gs.generate_RGBD_point_cloud(pose, max_depth=None)
+    assert mask2.all() and torch.equal(pts2, pts)
+
+
+def test_render_rgbd_without_fill_and_with_partial_outputs():
+    """sas_render_rgbd: raw expected depth (no fill) unprojected; points / mask individually optional."""
+    import ctypes
+    from sim_a_splat_amd import _capi
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    sc = make_scene(3000, seed=77, log_scale_mean=float(np.log(0.03)))
+    cam = ring_camera(97, 61, 80.0, yaw_deg=10.0)
+    r = Rasterizer("cuda:0")
+    r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
+    out = r.render_rgbd(cam.viewmat, cam.K, 97, 61, BG, max_depth=2.9, depth_fill_max=False)
+    ref = oracle.render_scene(sc, cam, background=BG, depth_mode=0)
+    assert np.array_equal(out["depth"].cpu().numpy(), ref["depth"]) and np.array_equal(out["rgb"].cpu().numpy(), ref["rgb"])
+    opts, omask = oracle.unproject(ref["depth"], cam.K, max_depth=2.9)
+    assert np.array_equal(out["points"].cpu().numpy(), opts) and np.array_equal(out["mask"].cpu().numpy(), omask)
+    # mask only / points only, and the error path: points without depth
+    L = _capi.lib()
+    V = np.ascontiguousarray(cam.viewmat, np.float32)
+    Kc = np.ascontiguousarray(cam.K, np.float32)
+    depth = torch.empty((61, 97, 1), device="cuda:0")
+    mask8 = torch.zeros((61, 97), dtype=torch.uint8, device="cuda:0")
+    md = ctypes.c_float(2.9)
+    rc = L.sas_render_rgbd(r._ctx, V.ctypes.data, Kc.ctypes.data, 97, 61, None, 0, ctypes.addressof(md), None, None,
+                           depth.data_ptr(), None, mask8.data_ptr(), None)
+    assert rc == 0 and np.array_equal(mask8.cpu().numpy().astype(bool), omask)
+    pts = torch.empty((61, 97, 3), device="cuda:0")
+    rc = L.sas_render_rgbd(r._ctx, V.ctypes.data, Kc.ctypes.data, 97, 61, None, 0, None, None, None, None,
+                           pts.data_ptr(), None, None)
+    assert rc == _capi.SAS_ERR_INVALID if hasattr(_capi, "SAS_ERR_INVALID") else rc == -1
+    assert b"depth" in L.sas_last_error(r._ctx)
 
 
 def _fake_msg(rng, n_links, robot_num=3):
@@ -103,4 +139,49 @@ def test_door_b_handler_groups_and_get_render():
         assert np.array_equal(got, ref["rgb8"])
         seen.append(ref["n_visible"])
     assert max(seen) > 100          # the viewport camera looks at the scene (the link camera may not)
+    h.scene.close()
+
+
+def test_door_b_with_the_shipped_masks_and_icp(golden_dir):
+    """cfg2 variant: N = 113,831 synthetic Gaussians (the count of robots-scene-v2) partitioned by
+    the reference's own xarm6-1 link masks, its ICP similarity, URDF-style FK, 640x480 frames."""
+    from sim_a_splat_amd import urdf_fk
+    from sim_a_splat_amd.covariance import compute_cov, sh2rgb
+    from sim_a_splat_amd.handler import SplatHandler
+    with np.load(golden_dir / "scene_assets_xarm6_1.npz") as z:
+        a = {k: z[k] for k in z.files}
+    n = int(a["n"])
+    masks = {str(k): np.unpackbits(b, count=n).astype(bool) for k, b in zip(a["link_names"], a["mask_bits"])}
+    rng = np.random.default_rng(11)
+    sc = make_scene(n, seed=2, log_scale_mean=float(np.log(0.012)))
+    covs = compute_cov(torch.from_numpy(sc.quats), torch.from_numpy(sc.scales)).numpy()
+    colors = np.clip(sh2rgb(torch.from_numpy(sc.sh[:, 0])).numpy(), 0, 1)
+    chain = "".join(f'<link name="l{i}"><visual><geometry><mesh filename="l{i}.obj"/></geometry></visual></link>' for i in range(7))
+    chain += "".join(f'<joint name="j{i}" type="revolute"><parent link="l{i - 1}"/><child link="l{i}"/>'
+                     f'<origin xyz="0.05 0 0.1" rpy="{0.3 * i} 0 0"/><axis xyz="0 0 1"/></joint>' for i in range(1, 7))
+    fk = urdf_fk.visual_mesh_fk(urdf_fk.load(f"<robot>{chain}</robot>"), a["joint_config"])
+    assert len(fk) == 7
+    h = SplatHandler(sc.means, covs, colors, sc.opacities, masks, a["icp_transformation"], fk, device=0)
+    msg = _fake_msg(rng, 7)
+    h.draw_handler(msg)
+    cam_q, cam_p = (0.0, 1.0, 0.0, 0.0), (0.0, 0.0, 3.0)
+    frame = h.render([(np.array(cam_q), np.array(cam_p))], [[480, 640]])[0]
+    assert frame.shape == (480, 640, 3) and frame.dtype == np.uint8
+    # oracle: registration order = links (a Gaussian in two masks is registered twice), then the rest
+    idx = [np.nonzero(masks[f"link{i}"])[0] for i in range(7)]
+    rest = np.nonzero(~np.logical_or.reduce(list(masks.values())))[0]
+    order = np.concatenate(idx + [rest])
+    group_of = np.concatenate([np.full(len(ix), i, np.uint8) for i, ix in enumerate(idx)] + [np.full(len(rest), 7, np.uint8)])
+    s, Ri, ti = poses.decompose_icp(a["icp_transformation"])
+    Rt = []
+    for i in range(7):
+        R, t = ref_math.link_splat_pose(Ri, ti, s, fk[i][:3, :3], fk[i][:3, 3], msg.quaternion[i], msg.position[i])
+        Rt.append(poses.rt_to_row12(poses.quat_wxyz_to_matrix(poses.matrix_to_quat_wxyz(R)), t))
+    Rt.append(poses.rt_to_row12(np.eye(3), np.zeros(3)))
+    cov6 = np.stack([covs[:, 0, 0], covs[:, 0, 1], covs[:, 0, 2], covs[:, 1, 1], covs[:, 1, 2], covs[:, 2, 2]], 1)[order]
+    V, K = h.scene._view_and_K(480, 640, cam_q, cam_p, h.scene.camera.fov)
+    ref = oracle.render(sc.means[order], sc.opacities[order], colors[order], V, K, 640, 480, cov6=cov6, sh_degree=-1,
+                        group_id=group_of, group_Rt=np.stack(Rt), background=(0, 0, 0), want_rgb8=True)
+    assert ref["n_visible"] > 50_000
+    assert np.array_equal(frame, ref["rgb8"])
     h.scene.close()

@@ -119,6 +119,24 @@ def test_rgb8_and_depth_fill_modes(golden_dir):
     assert np.array_equal(b["depth"][~empty], a["depth"][~empty])
 
 
+def test_unproject_matches_the_reference_torch_expression():
+    """nerfstudio_utils.py:424-445 evaluated with torch on the CPU (int64 meshgrid, f32 K) is
+    bit-identical to the oracle's C loop."""
+    import torch
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    depth = rng.uniform(0.0, 4.0, size=(H, W, 1)).astype(np.float32)
+    depth[3, 4] = 0.0
+    K = np.array([[61.25, 0, 26.5], [0, 59.75, 18.25], [0, 0, 1]], np.float32)
+    Kt, d = torch.from_numpy(K), torch.from_numpy(depth).squeeze()
+    U, V = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy")
+    ref = torch.stack(((U - Kt[0, 2]) * d / Kt[0, 0], (V - Kt[1, 2]) * d / Kt[1, 1], d), dim=-1)
+    pts, mask = oracle.unproject(depth, K, max_depth=1.5)
+    assert ref.dtype == torch.float32 and np.array_equal(pts, ref.numpy())
+    assert np.array_equal(mask, (d < 1.5).numpy())
+    assert oracle.unproject(depth, K, max_depth=None)[1].all()
+
+
 # ---- in-tree rows pinned by the reference's own module (fixtures generated by oracle/make_golden.py)
 def test_ref_math_compute_cov_matches_reference_fixture(golden_dir):
     g = np.load(golden_dir / "compute_cov.npz")
