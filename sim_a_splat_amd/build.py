@@ -37,6 +37,11 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB
     cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           # the SLP vectorizer pairs scalar f32 ops into v_pk_*_f32 (1.4x the issue cost of a scalar op on
+           # gfx950, tools/microbench/pk_f32_rate.hip) plus the moves that assemble their operands: a net
+           # loss in the compositing loop (+4.4 % frames/s at config 3 without it)
+           "-fno-slp-vectorize",
+           *os.environ.get("SAS_HIPCC_FLAGS", "").split(),   # experiments only
            "-x", "hip", *map(str, SOURCES), "-o", str(LIB)]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

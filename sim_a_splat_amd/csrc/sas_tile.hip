@@ -400,13 +400,12 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 // exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
 // the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
-DEV float c_expf_neg_small(float x)
+DEV float c_expf_neg_small(float x, float e5 /* 0.0013400432653725147f, pinned in a register */)
 {
     const float t = x * 1.4426950408889634f;
     const float n = __builtin_rintf(t);
     const float fr = t - n;
-    float p = 0.0013400432653725147f;
-    p = fma_(p, fr, 0.009676037356257439f);
+    float p = fma_(e5, fr, 0.009676037356257439f);
     p = fma_(p, fr, 0.05550327152013779f);
     p = fma_(p, fr, 0.2402210682630539f);
     p = fma_(p, fr, 0.6931471824645996f);
@@ -414,37 +413,35 @@ DEV float c_expf_neg_small(float x)
     return __builtin_ldexpf(p, (int)n);
 }
 
-// One splat onto one pixel.  `cand` = sigma >= 0 and sigma <= thr (sigma > thr implies
-// alpha < 1/255 with a margin far above rounding: same decision as the contract's alpha test).
-// Returns true when the pixel terminated on this splat (T' <= 1e-4: the splat is not added).
-template <bool FAST_EXP>
-DEV bool blend_one(PixState &p, bool cand, float sigma, float op, float cr, float cg, float cb, float dep)
+// Lane selects under an explicit wave mask (SGPR pair): dst = mask[lane] ? b : a.  The compiler
+// otherwise rebuilds lane predicates from bools with extra v_cndmask/v_cmp pairs.
+typedef unsigned long long wmask;
+DEV float sel_mask(float a, float b, wmask m)
 {
-    float E;
-    if (FAST_EXP) E = __expf(-sigma);
-    else E = c_expf_neg_small(-sigma);
-    const float alpha = fminf(kMaxAlpha, op * E);
-    const bool keep = cand && !(alpha < kAlphaThr);
-    const float nT = p.T * (1.0f - alpha);
-    const bool stop = keep && (nT <= kTStop);
-    const bool upd = keep && !stop;
-    // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite colours and
-    // depths of the path, so one select on the weight replaces four on the accumulators
-    const float vis = upd ? alpha * p.T : 0.0f;
-    p.r = fma_(cr, vis, p.r);
-    p.g = fma_(cg, vis, p.g);
-    p.b = fma_(cb, vis, p.b);
-    p.d = fma_(dep, vis, p.d);
-    p.T = upd ? nT : p.T;
-    p.px = stop ? kDeadPx : p.px;
-    return stop;
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+DEV float sel_mask_or_zero(float b, wmask m)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(b), "s"(m));
+    return r;
+}
+// a constant pinned in a VGPR (the compiler would re-materialise it with a v_mov inside the loop:
+// an SGPR cannot sit beside the literal of v_fmaak on gfx9's one-read constant bus)
+DEV float vgpr_const(unsigned bits)
+{
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(bits));
+    return r;
 }
 
 // LDS of the compositing loop: one staged batch of 256 records + per-wave compacted queues.
 struct BlendLds {
     float4 *q0, *q1, *q2;       // [256] each
     unsigned *mask;             // [256]
-    unsigned short *queue;      // [4][256]
+    unsigned short *queue;      // [4][256] byte offsets (16 * entry) into q0/q1/q2
 };
 constexpr int kBlendLdsBytes = 3 * 256 * 16 + 256 * 4 + 4 * 256 * 2;   // 15360
 
@@ -462,6 +459,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     bool have = false;
+    const float sE5 = vgpr_const(0x3aafa464u);   // leading exp coefficient
     // only issues the loads: nothing here may depend on their results
     auto fetch = [&](int at) {
         const int idx = at + tid;
@@ -481,7 +479,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
         if (__syncthreads_and(wdone)) { all_done = true; break; }
         unsigned ment = 0u;
         if (have) ment = quadrant_mask(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
-        L.q0[tid] = ra; L.q1[tid] = rb; L.q2[tid] = rc; L.mask[tid] = ment;
+        // q1 is staged as (conic c, threshold, opacity, depth): the loop header needs the first two
+        L.q0[tid] = ra; L.q1[tid] = make_float4(rb.x, rb.z, rb.y, rb.w); L.q2[tid] = rc; L.mask[tid] = ment;
         __syncthreads();
         if (at + 256 < count) fetch(at + 256);   // next batch in flight while this one is blended
         if (!wdone) {
@@ -493,19 +492,44 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
                 const int e = j * 64 + lane;
                 const bool has = e < cnt && ((L.mask[e] >> wv) & 1u);
                 const unsigned long long m = __ballot(has);
-                if (has) queue[qn + (int)__popcll(m & lt_mask)] = (unsigned short)e;
+                if (has) queue[qn + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
                 qn += (int)__popcll(m);
             }
+            const char *q0b = reinterpret_cast<const char *>(L.q0);
+            const char *q1b = reinterpret_cast<const char *>(L.q1);
+            const char *q2b = reinterpret_cast<const char *>(L.q2);
             for (int k = 0; k < qn; ++k) {
-                const int e = queue[k];
-                const float4 A = L.q0[e], B = L.q1[e];
+                const unsigned off = queue[k];
+                const float4 A = *reinterpret_cast<const float4 *>(q0b + off);
+                const float2 Bh = *reinterpret_cast<const float2 *>(q1b + off);
                 const float dx = A.x - p.px, dy = A.y - py;
-                const float sg = fma_(0.5f, fma_(B.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
-                const bool cand = sg >= 0.0f && sg <= B.z;
-                if (__any(cand)) {
-                    const float4 C = L.q2[e];
-                    const bool stop = blend_one<FAST_EXP>(p, cand, sg, B.y, C.x, C.y, C.z, B.w);
-                    if (__any(stop) && __all(p.px >= kDeadPx)) break;
+                const float sg = fma_(0.5f, fma_(Bh.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
+                // candidates: sigma >= 0 and sigma <= thr (sigma > thr implies alpha < 1/255 with a margin
+                // far above rounding: the same decision as the contract's alpha test)
+                const wmask candm = __ballot(sg >= 0.0f) & __ballot(sg <= Bh.y);
+                if (candm) {
+                    const float2 Bt = *reinterpret_cast<const float2 *>(q1b + off + 8);   // opacity, depth
+                    const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
+                    float E;
+                    if (FAST_EXP) E = __expf(-sg);
+                    else E = c_expf_neg_small(-sg, sE5);
+                    const float alpha = fminf(kMaxAlpha, Bt.x * E);
+                    const wmask keepm = candm & ~__ballot(alpha < kAlphaThr);
+                    const float nT = p.T * (1.0f - alpha);
+                    const wmask stopm = keepm & __ballot(nT <= kTStop);   // the splat that ends a pixel is not added
+                    const wmask updm = keepm & ~stopm;
+                    // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
+                    // colours and depths of the path, so one select on the weight replaces four
+                    const float vis = sel_mask_or_zero(alpha * p.T, updm);
+                    p.r = fma_(C.x, vis, p.r);
+                    p.g = fma_(C.y, vis, p.g);
+                    p.b = fma_(C.z, vis, p.b);
+                    p.d = fma_(Bt.y, vis, p.d);
+                    p.T = sel_mask(p.T, nT, updm);
+                    if (stopm) {   // rare: some pixel terminated on this splat
+                        p.px = sel_mask(p.px, kDeadPx, stopm);
+                        if (__all(p.px >= kDeadPx)) break;
+                    }
                 }
             }
             wdone = __all(p.px >= kDeadPx);
@@ -595,11 +619,21 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 // ================================================================================================
 // Production path: lazy depth ordering fused with compositing
 // ================================================================================================
-constexpr int kChunk = 1024;          // entries ordered and composited per round
+// (the SAS_TUNE_* macros exist for A/B builds only: SAS_HIPCC_FLAGS="-DSAS_TUNE_CHUNK=2048" python -m sim_a_splat_amd.build)
+#ifndef SAS_TUNE_CHUNK
+#define SAS_TUNE_CHUNK 1024
+#endif
+#ifndef SAS_TUNE_OCC
+#define SAS_TUNE_OCC 6
+#endif
+#ifndef SAS_TUNE_U
+#define SAS_TUNE_U 8
+#endif
+constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per round
 constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
-__global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
+__global__ __launch_bounds__(kLazyThreads, SAS_TUNE_OCC) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
                                                              const int *perm, int ablate)
 {
     // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
@@ -664,7 +698,7 @@ __global__ __launch_bounds__(kLazyThreads, 6) void k_tile_lazy(const SasParams *
         if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
     } else if (n > kChunk) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
-        constexpr int U = 8;
+        constexpr int U = SAS_TUNE_U;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         s_hist[tid] = 0u;
         __syncthreads();
