@@ -56,7 +56,7 @@ struct Slot {
     RenderArgs args;
     hipStream_t fs = nullptr;
     SasSortStreams sort_streams{};
-    hipEvent_t start = nullptr, done = nullptr;
+    hipEvent_t start = nullptr, done = nullptr, front_done = nullptr;
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
     unsigned *stats_host = nullptr;  // pinned, 8 words
     Scratch scr;
@@ -102,6 +102,15 @@ struct sas_ctx {
     hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
     bool has_frame = false;
     bool use_graphs = true;         // SAS_NO_GRAPH=1 disables frame graphs
+    // Stage pipelining (SAS_PIPELINE=1): binning (project, scan, scatter) of every frame on s_front,
+    // tile kernel + tail on s_tile.  Binning is HBM/latency-bound, the tile kernel VALU-bound: with
+    // both streams in order, the tile kernels run back to back while the next frame is binned.
+    int pipeline = 0;
+    hipStream_t s_front = nullptr, s_tile = nullptr;
+    // Frames that may EXECUTE at once (<= n_slots).  With more slots than that, the extra frames
+    // are queued on the GPU behind done events, so no host round trip sits between a frame
+    // finishing and the next one starting.
+    int run_depth = 0;   // 0: same as n_slots
     uint64_t scene_version = 0;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
@@ -251,7 +260,7 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
 }
 
 // The frame's work on stream `st`: parameter block, counters, the five stages, stats read-back.
-int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
+int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t st_tile = nullptr)
 {
     const RenderArgs &a = sl.args;
     const SasCam &cam = sl.cam;
@@ -271,6 +280,11 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing)
     sas_launch_scatter(st, c->scene, cam.tw, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
     const bool full = (a.flags & SAS_FULL_SORT) != 0;
+    if (st_tile && st_tile != st) {   // pipelined: the rest of the frame runs on the tile stream
+        HIP_TRY(c, hipEventRecord(sl.front_done, st));
+        HIP_TRY(c, hipStreamWaitEvent(st_tile, sl.front_done, 0));
+        st = st_tile;
+    }
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
@@ -323,14 +337,21 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     hp.out.points = a.points; hp.out.mask = a.mask;
     hp.out.max_depth = a.max_depth; hp.out.use_max_depth = a.use_max_depth ? 1 : 0;
 
-    hipStream_t st = sl.fs;
     const bool timing = (a.flags & SAS_TIMING) != 0;
+    const bool piped = c->pipeline && !timing && !(a.flags & SAS_FULL_SORT);
+    hipStream_t st = piped ? c->s_front : sl.fs;
+    hipStream_t st_end = piped ? c->s_tile : sl.fs;
     // start after whatever the caller has enqueued on its stream so far
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    if (c->run_depth > 0 && c->run_depth < c->n_slots) {
+        const int me = (int)(&sl - c->slots);
+        Slot &gate = c->slots[(me + c->n_slots - c->run_depth) % c->n_slots];   // frame j - run_depth
+        HIP_TRY(c, hipStreamWaitEvent(st, gate.done, 0));
+    }
     bool launched = false;
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
-    if (!timing && !ttiles && c->use_graphs) {
+    if (!timing && !ttiles && !piped && c->use_graphs) {
         Slot::GraphKey key;
         key.W = a.W; key.H = a.H;
         key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
@@ -363,13 +384,13 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
         }
     }
     if (!launched) {
-        rc = enqueue_body(c, sl, st, timing);
+        rc = enqueue_body(c, sl, st, timing, st_end);
         if (rc) return rc;
         HIP_TRY(c, hipGetLastError());
     }
     sl.timed = timing;
     sl.timed_tiles = ttiles && !timing && !(a.flags & SAS_FULL_SORT);
-    HIP_TRY(c, hipEventRecord(sl.done, st));
+    HIP_TRY(c, hipEventRecord(sl.done, st_end));
     sl.busy = true;
     c->has_frame = true;
     return SAS_OK;
@@ -456,12 +477,22 @@ int sas_create(int device, sas_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= kMaxSlots) c->n_slots = v;
     }
+    if (const char *e = getenv("SAS_PIPELINE")) c->pipeline = atoi(e);
+    if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
+    if (c->pipeline) {
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int prio = getenv("SAS_PRIO") ? atoi(getenv("SAS_PRIO")) : 0;   // 1: tile stream first, 2: binning first
+        ok = ok && hipStreamCreateWithPriority(&c->s_front, hipStreamNonBlocking, prio == 2 ? hi : (prio == 1 ? lo : 0)) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->s_tile, hipStreamNonBlocking, prio == 1 ? hi : (prio == 2 ? lo : 0)) == hipSuccess;
+    }
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&sl.params_host, sizeof(SasParams)) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&sl.fs, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         for (auto &sd : sl.sort_streams.side) ok = ok && hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.sort_streams.fork, hipEventDisableTiming) == hipSuccess;
@@ -480,6 +511,8 @@ int sas_destroy(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
+    for (hipStream_t *ps : {&c->s_front, &c->s_tile})
+        if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
     for (Slot &sl : c->slots) {
         if (sl.fs) (void)hipStreamSynchronize(sl.fs);
         for (auto &sd : sl.sort_streams.side)
@@ -494,6 +527,7 @@ int sas_destroy(sas_ctx *c)
         release(sl.params_dev);
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.front_done) (void)hipEventDestroy(sl.front_done);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,

@@ -388,6 +388,47 @@ DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B,
     return m;
 }
 
+// 16-bit mask of the 4x4-pixel blocks of tile (tx,ty) the Gaussian can reach.  Bit = cx + 4 cy.
+// sqrt(sigma) is a seminorm N (the conic is positive semi-definite), so for a pixel p of a block
+// with centre c:  N(p - m) >= N(c - m) - N(p - c) >= N(c - m) - r, where r bounds N over the
+// block's half extent (|vx|, |vy| <= 1.5 between pixel centres).  The block is dropped when
+// sigma(c - m) > (sqrt(thr + 0.05) + r)^2: no pixel of it can pass the loop's `sigma <= thr`.
+// The 0.05 margin is four orders of magnitude above any rounding difference between this
+// estimate and the contract's per-pixel sigma, so dropping a block never changes a pixel.
+DEV unsigned block_mask16(int tx, int ty, float mx, float my, float A, float B, float C, float thr)
+{
+    const float r2 = 1.125f * (A + C) + 2.25f * fabsf(B);
+    const float lim = sqrtf(thr + 0.05f) + sqrtf(r2);
+    const float lim2 = lim * lim;
+    float hx[4], bx[4], hy[4], dy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = mx - ((float)(tx * SAS_TILE + 4 * k) + 2.0f);
+        hx[k] = (0.5f * A) * dx * dx;
+        bx[k] = B * dx;
+        dy[k] = my - ((float)(ty * SAS_TILE + 4 * k) + 2.0f);
+        hy[k] = (0.5f * C) * dy[k] * dy[k];
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) {
+            const float sc = fma_(bx[cx], dy[cy], hx[cx] + hy[cy]);
+            if (!(sc > lim2)) m |= 1u << (cx + 4 * cy);
+        }
+    return m;
+}
+
+// Pixel of (wave, lane) inside the tile: wave w owns the 8x8 quadrant (w & 1, w >> 1); its four
+// 16-lane groups own the quadrant's 4x4 blocks, so that each group can walk its own splat queue.
+DEV void pixel_of(int wv, int lane, int &ox, int &oy)
+{
+    const int g = lane >> 4, q = lane & 15;
+    ox = (wv & 1) * 8 + (g & 1) * 4 + (q & 3);
+    oy = (wv >> 1) * 8 + (g >> 1) * 4 + (q >> 2);
+}
+
 // Per-pixel compositing state.  A terminated pixel (transmittance test fired, or outside the image)
 // is parked at x = kDeadPx: every later sigma is then huge or NaN and fails `sigma <= thr` by
 // itself, so the inner loop carries no "done" flag.
@@ -437,20 +478,51 @@ DEV float vgpr_const(unsigned bits)
     return r;
 }
 
-// LDS of the compositing loop: one staged batch of 256 records + per-wave compacted queues.
+#ifdef SAS_TUNE_STATS
+// A/B builds only: [0] wave-iterations of the compositing loop, [1] of those with a candidate lane,
+// [2] candidate lanes, [3] lanes that composited, [4] staged entries, [5] queued (entry, wave) pairs
+__device__ unsigned long long g_dbg[8];
+extern "C" int sas_debug_counters(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define DBG_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define DBG_ADD(i, v) do { } while (0)
+#endif
+
+// LDS of the compositing loop: one staged batch of 256 records (+ one sentinel record that no
+// pixel accepts) and, per wave, one compacted queue for each of its four 4x4 blocks.
+constexpr int kStage = 257;
 struct BlendLds {
-    float4 *q0, *q1, *q2;       // [256] each
-    unsigned *mask;             // [256]
-    unsigned short *queue;      // [4][256] byte offsets (16 * entry) into q0/q1/q2
+    float4 *q0, *q1, *q2;       // [257] each
+    unsigned *mask;             // [256] 16 block bits per staged entry
+    unsigned short *queue;      // [4 waves][4 blocks][256] byte offsets (16 * entry) into q0/q1/q2
 };
-constexpr int kBlendLdsBytes = 3 * 256 * 16 + 256 * 4 + 4 * 256 * 2;   // 15360
+constexpr int kBlendLdsBytes = 3 * kStage * 16 + 256 * 4 + 16 * 256 * 2;   // 21552
+DEV BlendLds blend_lds(unsigned char *raw)
+{
+    BlendLds L;
+    L.q0 = reinterpret_cast<float4 *>(raw);
+    L.q1 = L.q0 + kStage;
+    L.q2 = L.q1 + kStage;
+    L.mask = reinterpret_cast<unsigned *>(L.q2 + kStage);
+    L.queue = reinterpret_cast<unsigned short *>(L.mask + 256);
+    return L;
+}
 
 // Composite entries [0, count) of a depth-ordered list onto this thread's pixel.  Wave w owns the
-// 8x8 quadrant w of the tile, one pixel per lane.  Per batch of 256 entries every thread stages
-// one 48-byte record with its quadrant mask; each wave ballots the entries that name its quadrant
-// into its own queue and walks only those, front to back.  Returns true when every pixel of the
-// tile has terminated (uniform over the workgroup).  `slot_at(i)` gives the storage slot of
-// entry i.
+// 8x8 quadrant w of the tile, its 16-lane group g the quadrant's 4x4 block g (pixel_of).  Per batch
+// of 256 entries every thread stages one 48-byte record with its 16-bit block mask; each wave
+// ballots, per block, the entries that name it into that block's queue, and the four groups walk
+// their own queues in lockstep, front to back (a group that runs out reads the sentinel record,
+// which no pixel accepts).  Returns true when every pixel of the tile has terminated (uniform over
+// the workgroup).  `slot_at(i)` gives the storage slot of entry i.
 template <bool FAST_EXP, typename SlotAt>
 DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float py, int count, SlotAt slot_at,
                      const BlendLds &L, PixState &p, bool &wdone)
@@ -473,33 +545,56 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
         }
     };
     if (count > 0) fetch(0);
+    if (tid == 0) {   // sentinel record: sigma = 0 against threshold -1
+        L.q0[256] = make_float4(0, 0, 0, 0);
+        L.q1[256] = make_float4(0, -1.0f, 0, 0);
+        L.q2[256] = make_float4(0, 0, 0, 0);
+    }
+    // this lane's block: bit in the entry masks, and its queue
+    const int grp = lane >> 4;
+    const int my_bit = ((wv & 1) * 2 + (grp & 1)) + 4 * ((wv >> 1) * 2 + (grp >> 1));
+    unsigned short *wq = L.queue + wv * 1024;        // this wave's four queues
+    const unsigned short *myq = wq + grp * 256;
+    const char *q0b = reinterpret_cast<const char *>(L.q0);
+    const char *q1b = reinterpret_cast<const char *>(L.q1);
+    const char *q2b = reinterpret_cast<const char *>(L.q2);
     bool all_done = false;
     for (int at = 0; at < count; at += 256) {
         // the previous batch is fully consumed; leave once every wave has terminated
         if (__syncthreads_and(wdone)) { all_done = true; break; }
         unsigned ment = 0u;
-        if (have) ment = quadrant_mask(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+        if (have) ment = block_mask16(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
         // q1 is staged as (conic c, threshold, opacity, depth): the loop header needs the first two
         L.q0[tid] = ra; L.q1[tid] = make_float4(rb.x, rb.z, rb.y, rb.w); L.q2[tid] = rc; L.mask[tid] = ment;
+        if (!wdone) {   // all four queues of the wave start as sentinels (2 KiB: 32 bytes per lane)
+            uint4 *z = reinterpret_cast<uint4 *>(wq) + 2 * lane;
+            const unsigned sw = (256u << 4) | ((256u << 4) << 16);
+            z[0] = make_uint4(sw, sw, sw, sw);
+            z[1] = make_uint4(sw, sw, sw, sw);
+        }
         __syncthreads();
         if (at + 256 < count) fetch(at + 256);   // next batch in flight while this one is blended
         if (!wdone) {
             const int cnt = (count - at) < 256 ? (count - at) : 256;
-            unsigned short *queue = L.queue + wv * 256;
-            int qn = 0;
+            int qn[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = j * 64 + lane;
-                const bool has = e < cnt && ((L.mask[e] >> wv) & 1u);
-                const unsigned long long m = __ballot(has);
-                if (has) queue[qn + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
-                qn += (int)__popcll(m);
+                const unsigned me = e < cnt ? L.mask[e] : 0u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int bit = ((wv & 1) * 2 + (g & 1)) + 4 * ((wv >> 1) * 2 + (g >> 1));
+                    const bool has = (me >> bit) & 1u;
+                    const unsigned long long m = __ballot(has);
+                    if (has) wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
+                    qn[g] += (int)__popcll(m);
+                }
             }
-            const char *q0b = reinterpret_cast<const char *>(L.q0);
-            const char *q1b = reinterpret_cast<const char *>(L.q1);
-            const char *q2b = reinterpret_cast<const char *>(L.q2);
-            for (int k = 0; k < qn; ++k) {
-                const unsigned off = queue[k];
+            const int kmax = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
+            DBG_ADD(5, qn[0] + qn[1] + qn[2] + qn[3]);
+            if (wv == 0) DBG_ADD(4, cnt);
+            for (int k = 0; k < kmax; ++k) {
+                const unsigned off = myq[k];
                 const float4 A = *reinterpret_cast<const float4 *>(q0b + off);
                 const float2 Bh = *reinterpret_cast<const float2 *>(q1b + off);
                 const float dx = A.x - p.px, dy = A.y - py;
@@ -507,7 +602,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
                 // candidates: sigma >= 0 and sigma <= thr (sigma > thr implies alpha < 1/255 with a margin
                 // far above rounding: the same decision as the contract's alpha test)
                 const wmask candm = __ballot(sg >= 0.0f) & __ballot(sg <= Bh.y);
+                DBG_ADD(0, 1);
                 if (candm) {
+                    DBG_ADD(1, 1);
+                    DBG_ADD(2, __popcll(candm));
                     const float2 Bt = *reinterpret_cast<const float2 *>(q1b + off + 8);   // opacity, depth
                     const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
                     float E;
@@ -518,6 +616,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
                     const float nT = p.T * (1.0f - alpha);
                     const wmask stopm = keepm & __ballot(nT <= kTStop);   // the splat that ends a pixel is not added
                     const wmask updm = keepm & ~stopm;
+                    DBG_ADD(3, __popcll(updm));
                     // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
                     // colours and depths of the path, so one select on the weight replaces four
                     const float vis = sel_mask_or_zero(alpha * p.T, updm);
@@ -590,18 +689,14 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
     __shared__ unsigned s_wmax[4];
     const SasCam &c = P->cam;
     const SasOutputs o = P->out;
-    BlendLds L;
-    L.q0 = reinterpret_cast<float4 *>(s_raw);
-    L.q1 = L.q0 + 256;
-    L.q2 = L.q1 + 256;
-    L.mask = reinterpret_cast<unsigned *>(L.q2 + 256);
-    L.queue = reinterpret_cast<unsigned short *>(L.mask + 256);
+    const BlendLds L = blend_lds(s_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
         const int tile = tl[oi];
         const int tx = tile % c.tw, ty = tile / c.tw;
-        const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
-        const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
+        int ox, oy;
+        pixel_of(wv, lane, ox, oy);
+        const int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
         const bool inside = ix < c.W && iy < c.H;
         PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
         bool wdone = __all(!inside);
@@ -624,7 +719,7 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 #define SAS_TUNE_CHUNK 1024
 #endif
 #ifndef SAS_TUNE_OCC
-#define SAS_TUNE_OCC 6
+#define SAS_TUNE_OCC 5
 #endif
 #ifndef SAS_TUNE_U
 #define SAS_TUNE_U 8
@@ -633,32 +728,28 @@ constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per r
 constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
-__global__ __launch_bounds__(kLazyThreads, SAS_TUNE_OCC) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
+__global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC))) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
                                                              const int *perm, int ablate)
 {
     // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
     __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 15 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 21 KiB
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_wsum[4], s_wmax[4];
     __shared__ unsigned s_mn, s_mx, s_m;
     __shared__ int s_b1;
     const SasCam &c = P->cam;
     const SasOutputs o = P->out;
-    BlendLds L;
-    L.q0 = reinterpret_cast<float4 *>(s_raw);
-    L.q1 = L.q0 + 256;
-    L.q2 = L.q1 + 256;
-    L.mask = reinterpret_cast<unsigned *>(L.q2 + 256);
-    L.queue = reinterpret_cast<unsigned short *>(L.mask + 256);
+    const BlendLds L = blend_lds(s_raw);
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
 
     const int tile = f.tile_order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
-    const int ix = tx * SAS_TILE + (wv & 1) * 8 + (lane & 7);
-    const int iy = ty * SAS_TILE + (wv >> 1) * 8 + (lane >> 3);
+    int ox, oy;
+    pixel_of(wv, lane, ox, oy);
+    const int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
     const float py = (float)iy + 0.5f;
     const bool inside = ix < c.W && iy < c.H;
     PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
