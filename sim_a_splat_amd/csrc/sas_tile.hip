@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 // ================================================================================================
 // (the SAS_TUNE_* macros exist for A/B builds only: SAS_HIPCC_FLAGS="-DSAS_TUNE_CHUNK=2048" python -m sim_a_splat_amd.build)
 #ifndef SAS_TUNE_CHUNK
-#define SAS_TUNE_CHUNK 1024
+#define SAS_TUNE_CHUNK 512
 #endif
 #ifndef SAS_TUNE_OCC
 #define SAS_TUNE_OCC 5
