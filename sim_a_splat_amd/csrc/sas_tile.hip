@@ -593,39 +593,59 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
             const int kmax = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
             DBG_ADD(5, qn[0] + qn[1] + qn[2] + qn[3]);
             if (wv == 0) DBG_ADD(4, cnt);
-            for (int k = 0; k < kmax; ++k) {
-                const unsigned off = myq[k];
-                const float4 A = *reinterpret_cast<const float4 *>(q0b + off);
-                const float2 Bh = *reinterpret_cast<const float2 *>(q1b + off);
-                const float dx = A.x - p.px, dy = A.y - py;
-                const float sg = fma_(0.5f, fma_(Bh.x * dy, dy, (A.z * dx) * dx), (A.w * dx) * dy);
+            // Two queue entries per trip: their record loads, sigmas and exponentials are independent
+            // (one wave alone cannot hide the two dependent LDS round trips of an entry); only the
+            // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
+            for (int k = 0; k < kmax; k += 2) {
+                const unsigned off0 = myq[k], off1 = myq[k + 1];
+                const float4 A0 = *reinterpret_cast<const float4 *>(q0b + off0);
+                const float2 H0 = *reinterpret_cast<const float2 *>(q1b + off0);
+                const float4 A1 = *reinterpret_cast<const float4 *>(q0b + off1);
+                const float2 H1 = *reinterpret_cast<const float2 *>(q1b + off1);
+                const float dx0 = A0.x - p.px, dy0 = A0.y - py;
+                const float sg0 = fma_(0.5f, fma_(H0.x * dy0, dy0, (A0.z * dx0) * dx0), (A0.w * dx0) * dy0);
+                const float dx1 = A1.x - p.px, dy1 = A1.y - py;
+                const float sg1 = fma_(0.5f, fma_(H1.x * dy1, dy1, (A1.z * dx1) * dx1), (A1.w * dx1) * dy1);
                 // candidates: sigma >= 0 and sigma <= thr (sigma > thr implies alpha < 1/255 with a margin
                 // far above rounding: the same decision as the contract's alpha test)
-                const wmask candm = __ballot(sg >= 0.0f) & __ballot(sg <= Bh.y);
-                DBG_ADD(0, 1);
-                if (candm) {
-                    DBG_ADD(1, 1);
-                    DBG_ADD(2, __popcll(candm));
-                    const float2 Bt = *reinterpret_cast<const float2 *>(q1b + off + 8);   // opacity, depth
-                    const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
-                    float E;
-                    if (FAST_EXP) E = __expf(-sg);
-                    else E = c_expf_neg_small(-sg, sE5);
-                    const float alpha = fminf(kMaxAlpha, Bt.x * E);
-                    const wmask keepm = candm & ~__ballot(alpha < kAlphaThr);
-                    const float nT = p.T * (1.0f - alpha);
-                    const wmask stopm = keepm & __ballot(nT <= kTStop);   // the splat that ends a pixel is not added
-                    const wmask updm = keepm & ~stopm;
-                    DBG_ADD(3, __popcll(updm));
+                const wmask cand0 = __ballot(sg0 >= 0.0f) & __ballot(sg0 <= H0.y);
+                const wmask cand1 = __ballot(sg1 >= 0.0f) & __ballot(sg1 <= H1.y);
+                DBG_ADD(0, 2);
+                if (cand0 | cand1) {
+                    DBG_ADD(1, 2);
+                    DBG_ADD(2, __popcll(cand0) + __popcll(cand1));
+                    const float2 T0 = *reinterpret_cast<const float2 *>(q1b + off0 + 8);   // opacity, depth
+                    const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);
+                    const float2 T1 = *reinterpret_cast<const float2 *>(q1b + off1 + 8);
+                    const float4 C1 = *reinterpret_cast<const float4 *>(q2b + off1);
+                    float E0, E1;
+                    if (FAST_EXP) { E0 = __expf(-sg0); E1 = __expf(-sg1); }
+                    else { E0 = c_expf_neg_small(-sg0, sE5); E1 = c_expf_neg_small(-sg1, sE5); }
+                    const float al0 = fminf(kMaxAlpha, T0.x * E0);
+                    const float al1 = fminf(kMaxAlpha, T1.x * E1);
+                    // first entry
+                    const wmask keep0 = cand0 & ~__ballot(al0 < kAlphaThr);
+                    const float nT0 = p.T * (1.0f - al0);
+                    const wmask stop0 = keep0 & __ballot(nT0 <= kTStop);   // the splat that ends a pixel is not added
+                    const wmask upd0 = keep0 & ~stop0;
                     // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
                     // colours and depths of the path, so one select on the weight replaces four
-                    const float vis = sel_mask_or_zero(alpha * p.T, updm);
-                    p.r = fma_(C.x, vis, p.r);
-                    p.g = fma_(C.y, vis, p.g);
-                    p.b = fma_(C.z, vis, p.b);
-                    p.d = fma_(Bt.y, vis, p.d);
-                    p.T = sel_mask(p.T, nT, updm);
-                    if (stopm) {   // rare: some pixel terminated on this splat
+                    const float vis0 = sel_mask_or_zero(al0 * p.T, upd0);
+                    const float Tm = sel_mask(p.T, nT0, upd0);
+                    // second entry: a pixel the first one terminated takes nothing more
+                    const wmask keep1 = cand1 & ~__ballot(al1 < kAlphaThr) & ~stop0;
+                    const float nT1 = Tm * (1.0f - al1);
+                    const wmask stop1 = keep1 & __ballot(nT1 <= kTStop);
+                    const wmask upd1 = keep1 & ~stop1;
+                    DBG_ADD(3, __popcll(upd0) + __popcll(upd1));
+                    const float vis1 = sel_mask_or_zero(al1 * Tm, upd1);
+                    p.T = sel_mask(Tm, nT1, upd1);
+                    p.r = fma_(C1.x, vis1, fma_(C0.x, vis0, p.r));
+                    p.g = fma_(C1.y, vis1, fma_(C0.y, vis0, p.g));
+                    p.b = fma_(C1.z, vis1, fma_(C0.z, vis0, p.b));
+                    p.d = fma_(T1.y, vis1, fma_(T0.y, vis0, p.d));
+                    const wmask stopm = stop0 | stop1;
+                    if (stopm) {   // rare: some pixel terminated on these splats
                         p.px = sel_mask(p.px, kDeadPx, stopm);
                         if (__all(p.px >= kDeadPx)) break;
                     }
