@@ -50,6 +50,16 @@
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+int sas_oracle_num_threads(void);
+static inline int oc_thread_id(void)
+{
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
+}
+
 /* ---- contract transcendental functions ------------------------------------------------- */
 
 /* 2^f on [-0.5,0.5], degree-5 near-minimax, max rel. error 2.3e-7 after f32 rounding. */
@@ -63,18 +73,22 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 float sas_oracle_expf(float x)
 {
-    float t = x * OC_LOG2E;
-    t = fmaxf(t, -125.0f);
-    t = fminf(t, 126.0f);
-    float n = rintf(t); /* round-half-even, the hardware v_rndne_f32 */
-    float f = t - n;
+    /* argument clamped so that 2^n stays a normal number; n = round-half-even(x log2 e) is taken
+     * from the low mantissa bits of x log2 e + 1.5 * 2^23 (one fused multiply-add, the hardware
+     * v_fma_f32) and added into the exponent field of the polynomial's value */
+    const float magic = 12582912.0f;
+    x = fmaxf(x, -86.0f);
+    x = fminf(x, 86.0f);
+    float tm = fmaf(x, OC_LOG2E, magic);
+    float n = tm - magic;
+    float f = fmaf(x, OC_LOG2E, -n);
     float p = OC_E5;
     p = fmaf(p, f, OC_E4);
     p = fmaf(p, f, OC_E3);
     p = fmaf(p, f, OC_E2);
     p = fmaf(p, f, OC_E1);
     p = fmaf(p, f, OC_E0);
-    return ldexpf(p, (int)n);
+    return u2f(f2u(p) + (f2u(tm) << 23));
 }
 
 /* natural log for positive normal x: x = 2^e * m, m in [sqrt(1/2), sqrt(2)),
@@ -368,22 +382,41 @@ static int cmp_u64(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-/* T6 for one pixel */
-static inline void blend_pixel(const proj_t *P, const int32_t *ids, int64_t n, float px, float py,
+/* T6, per (Gaussian, tile): sigma as a polynomial in the tile-local pixel centre (x, y),
+ *   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
+ *   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2
+ * (algebraically gsplat's 0.5 (A dx^2 + C dy^2) + B dx dy with dx = mx - px; the conic is positive
+ * semi-definite, so gsplat's `sigma < 0` guard can only fire on rounding noise and is not part of
+ * the contract). */
+typedef struct { float k0, k1, k2, hA, hC, B; } tcoef_t;
+
+static inline void tile_coefs(const proj_t *g, float X0, float Y0, tcoef_t *t)
+{
+    float u = g->mx - X0, v = g->my - Y0;
+    float A = g->ca, B = g->cb, C = g->cc;
+    float hA = 0.5f * A, hC = 0.5f * C;
+    float bu = B * u;
+    t->k1 = -fmaf(A, u, B * v);
+    t->k2 = -fmaf(C, v, bu);
+    t->k0 = fmaf(hA * u, u, fmaf(hC * v, v, bu * v));
+    t->hA = hA; t->hC = hC; t->B = B;
+}
+
+/* T6 for one pixel; (x, y) = pixel centre relative to the tile origin */
+static inline void blend_pixel(const proj_t *P, const int32_t *ids, const tcoef_t *tc, int64_t n, float x, float y,
                                float out_acc[4], float *out_T)
 {
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, ad = 0.0f;
+    const float xx = x * x, yy = y * y, xy = x * y; /* exact: multiples of 0.25 below 256 */
     for (int64_t k = 0; k < n; ++k) {
         const proj_t *g = &P[ids[k]];
-        float dx = g->mx - px, dy = g->my - py;
-        float s = fmaf(g->cc * dy, dy, (g->ca * dx) * dx);
-        float sigma = fmaf(0.5f, s, (g->cb * dx) * dy);
-        if (sigma < 0.0f) continue;
+        const tcoef_t *t = &tc[k];
+        float sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
         float alpha = fminf(OC_MAX_ALPHA, g->opac * sas_oracle_expf(-sigma));
         if (alpha < OC_ALPHA_THRESHOLD) continue;
-        float next_T = T * (1.0f - alpha);
-        if (next_T <= OC_T_STOP) break;
         float vis = alpha * T;
+        float next_T = T - vis;
+        if (next_T <= OC_T_STOP) break;
         ar = fmaf(g->rgb[0], vis, ar);
         ag = fmaf(g->rgb[1], vis, ag);
         ab = fmaf(g->rgb[2], vis, ab);
@@ -450,12 +483,21 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         for (int64_t k = a; k < b; ++k) ids[k] = (int32_t)(uint32_t)(keys[k] & 0xffffffffu);
     }
 
+    /* per-thread scratch for the per-(Gaussian, tile) coefficients of the longest list */
+    int64_t max_len = 1;
+    for (int t = 0; t < tiles; ++t)
+        if (tcount[t + 1] - tcount[t] > max_len) max_len = tcount[t + 1] - tcount[t];
+    tcoef_t *tc_all = (tcoef_t *)malloc(sizeof(tcoef_t) * (size_t)max_len * (size_t)sas_oracle_num_threads());
+    if (!tc_all) { free(P); free(tcount); free(keys); free(ids); free(cursor); return -1; }
+
     float maxED = 0.0f;
 #pragma omp parallel for schedule(dynamic, 4) reduction(max : maxED)
     for (int t = 0; t < tiles; ++t) {
         int ty = t / c.tw, tx = t % c.tw;
         const int32_t *tl = ids + tcount[t];
         int64_t tn = tcount[t + 1] - tcount[t];
+        tcoef_t *tc = tc_all + (size_t)oc_thread_id() * (size_t)max_len;
+        for (int64_t k = 0; k < tn; ++k) tile_coefs(&P[tl[k]], (float)(tx * OC_TILE), (float)(ty * OC_TILE), &tc[k]);
         for (int yy = 0; yy < OC_TILE; ++yy) {
             int i = ty * OC_TILE + yy;
             if (i >= H) break;
@@ -463,7 +505,7 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
                 int j = tx * OC_TILE + xx;
                 if (j >= W) break;
                 float acc[4], T;
-                blend_pixel(P, tl, tn, (float)j + 0.5f, (float)i + 0.5f, acc, &T);
+                blend_pixel(P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f, acc, &T);
                 float a = 1.0f - T;
                 int64_t pix = (int64_t)i * W + j;
                 float ED = acc[3] / fmaxf(a, 1e-10f);
@@ -508,7 +550,7 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         memcpy(o_sorted_ids, ids, sizeof(int32_t) * (size_t)m);
     }
     if (stats) { stats[0] = n_vis; stats[1] = M; }
-    free(P); free(tcount); free(keys); free(ids); free(cursor);
+    free(P); free(tcount); free(keys); free(ids); free(cursor); free(tc_all);
     return 0;
 }
 

@@ -429,29 +429,41 @@ DEV void pixel_of(int wv, int lane, int &ox, int &oy)
     oy = (wv >> 1) * 8 + (g >> 1) * 4 + (q >> 2);
 }
 
-// Per-pixel compositing state.  A terminated pixel (transmittance test fired, or outside the image)
-// is parked at x = kDeadPx: every later sigma is then huge or NaN and fails `sigma <= thr` by
-// itself, so the inner loop carries no "done" flag.
-constexpr float kDeadPx = 1.0e30f;
+// Per-pixel compositing state.  x is the pixel centre relative to the tile origin.  A terminated
+// pixel (transmittance test fired, or outside the image) is parked at x = NaN: every later sigma is
+// then NaN and fails `sigma <= thr` by itself, so the inner loop carries no "done" flag.
 struct PixState {
     float T, r, g, b, d;
-    float px;
+    float x;
 };
+// loop-invariant powers of the pixel's tile-local centre (exact: multiples of 0.25 below 256)
+struct PixConst {
+    float y, xx, yy, xy;
+};
+DEV bool pix_dead(const PixState &p) { return p.x != p.x; }
+DEV PixState pix_init(bool inside, int ox) { return PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ox + 0.5f : __builtin_nanf("")}; }
+DEV PixConst pix_const(int ox, int oy)
+{
+    const float x = (float)ox + 0.5f, y = (float)oy + 0.5f;
+    return PixConst{y, x * x, y * y, x * y};
+}
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
-// exp for candidate lanes only: 0 <= sigma <= thr <= ln(255)+1e-3, so the contract's clamps on
-// the exponent are no-ops and are left out (identical bits, two VALU ops fewer).
+// Contract exp for candidate lanes only: -1e-2 < sigma <= thr <= ln(255)+1e-3, so the contract's
+// clamp on the argument is a no-op and is left out (identical bits).  n = round(x log2 e) is read off
+// the low mantissa bits of x log2 e + 1.5 * 2^23 and added straight into the exponent field.
 DEV float c_expf_neg_small(float x, float e5 /* 0.0013400432653725147f, pinned in a register */)
 {
-    const float t = x * 1.4426950408889634f;
-    const float n = __builtin_rintf(t);
-    const float fr = t - n;
+    const float magic = 12582912.0f;
+    const float tm = fma_(x, 1.4426950408889634f, magic);
+    const float n = tm - magic;
+    const float fr = fma_(x, 1.4426950408889634f, -n);
     float p = fma_(e5, fr, 0.009676037356257439f);
     p = fma_(p, fr, 0.05550327152013779f);
     p = fma_(p, fr, 0.2402210682630539f);
     p = fma_(p, fr, 0.6931471824645996f);
     p = fma_(p, fr, 1.0000001192092896f);
-    return __builtin_ldexpf(p, (int)n);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
 }
 
 // Lane selects under an explicit wave mask (SGPR pair): dst = mask[lane] ? b : a.  The compiler
@@ -524,7 +536,7 @@ DEV BlendLds blend_lds(unsigned char *raw)
 // which no pixel accepts).  Returns true when every pixel of the tile has terminated (uniform over
 // the workgroup).  `slot_at(i)` gives the storage slot of entry i.
 template <bool FAST_EXP, typename SlotAt>
-DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float py, int count, SlotAt slot_at,
+DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const PixConst pc, int count, SlotAt slot_at,
                      const BlendLds &L, PixState &p, bool &wdone)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -547,9 +559,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
     if (count > 0) fetch(0);
     if (tid == 0) {   // sentinel record: sigma = 0 against threshold -1
         L.q0[256] = make_float4(0, 0, 0, 0);
-        L.q1[256] = make_float4(0, -1.0f, 0, 0);
+        L.q1[256] = make_float4(0, 0, -1.0f, 0);
         L.q2[256] = make_float4(0, 0, 0, 0);
     }
+    const float X0 = (float)(tx * SAS_TILE), Y0 = (float)(ty * SAS_TILE);
     // this lane's block: bit in the entry masks, and its queue
     const int grp = lane >> 4;
     const int my_bit = ((wv & 1) * 2 + (grp & 1)) + 4 * ((wv >> 1) * 2 + (grp >> 1));
@@ -564,8 +577,23 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
         if (__syncthreads_and(wdone)) { all_done = true; break; }
         unsigned ment = 0u;
         if (have) ment = block_mask16(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
-        // q1 is staged as (conic c, threshold, opacity, depth): the loop header needs the first two
-        L.q0[tid] = ra; L.q1[tid] = make_float4(rb.x, rb.z, rb.y, rb.w); L.q2[tid] = rc; L.mask[tid] = ment;
+        // Contract T6: sigma as a polynomial in the tile-local pixel centre (x, y),
+        //   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
+        //   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2,
+        // five FMAs per pixel in the loop instead of nine operations on (dx, dy).
+        {
+            const float u = ra.x - X0, v = ra.y - Y0;
+            const float A = ra.z, B = ra.w, C = rb.x;
+            const float hA = 0.5f * A, hC = 0.5f * C;
+            const float bu = B * u;
+            const float k1 = -fma_(A, u, B * v);
+            const float k2 = -fma_(C, v, bu);
+            const float k0 = fma_(hA * u, u, fma_(hC * v, v, bu * v));
+            L.q0[tid] = make_float4(k0, k1, k2, hA);
+            L.q1[tid] = make_float4(hC, B, rb.z, rb.y);          // .z threshold, .w opacity
+            L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);     // colour, depth
+            L.mask[tid] = ment;
+        }
         if (!wdone) {   // all four queues of the wave start as sentinels (2 KiB: 32 bytes per lane)
             uint4 *z = reinterpret_cast<uint4 *>(wq) + 2 * lane;
             const unsigned sw = (256u << 4) | ((256u << 4) << 16);
@@ -598,60 +626,58 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, float
             // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
             for (int k = 0; k < kmax; k += 2) {
                 const unsigned off0 = myq[k], off1 = myq[k + 1];
-                const float4 A0 = *reinterpret_cast<const float4 *>(q0b + off0);
-                const float2 H0 = *reinterpret_cast<const float2 *>(q1b + off0);
-                const float4 A1 = *reinterpret_cast<const float4 *>(q0b + off1);
-                const float2 H1 = *reinterpret_cast<const float2 *>(q1b + off1);
-                const float dx0 = A0.x - p.px, dy0 = A0.y - py;
-                const float sg0 = fma_(0.5f, fma_(H0.x * dy0, dy0, (A0.z * dx0) * dx0), (A0.w * dx0) * dy0);
-                const float dx1 = A1.x - p.px, dy1 = A1.y - py;
-                const float sg1 = fma_(0.5f, fma_(H1.x * dy1, dy1, (A1.z * dx1) * dx1), (A1.w * dx1) * dy1);
-                // candidates: sigma >= 0 and sigma <= thr (sigma > thr implies alpha < 1/255 with a margin
-                // far above rounding: the same decision as the contract's alpha test)
-                const wmask cand0 = __ballot(sg0 >= 0.0f) & __ballot(sg0 <= H0.y);
-                const wmask cand1 = __ballot(sg1 >= 0.0f) & __ballot(sg1 <= H1.y);
+                const float4 K0 = *reinterpret_cast<const float4 *>(q0b + off0);
+                const float4 H0 = *reinterpret_cast<const float4 *>(q1b + off0);
+                const float4 K1 = *reinterpret_cast<const float4 *>(q0b + off1);
+                const float4 H1 = *reinterpret_cast<const float4 *>(q1b + off1);
+                const float sg0 = fma_(H0.y, pc.xy, fma_(H0.x, pc.yy, fma_(K0.w, pc.xx, fma_(K0.z, pc.y, fma_(K0.y, p.x, K0.x)))));
+                const float sg1 = fma_(H1.y, pc.xy, fma_(H1.x, pc.yy, fma_(K1.w, pc.xx, fma_(K1.z, pc.y, fma_(K1.y, p.x, K1.x)))));
+                // candidates: sigma <= thr (sigma > thr implies alpha < 1/255 with a margin far above
+                // rounding: the same decision as the contract's alpha test); NaN for a parked pixel
+                const wmask cand0 = __ballot(sg0 <= H0.z);
+                const wmask cand1 = __ballot(sg1 <= H1.z);
                 DBG_ADD(0, 2);
                 if (cand0 | cand1) {
                     DBG_ADD(1, 2);
                     DBG_ADD(2, __popcll(cand0) + __popcll(cand1));
-                    const float2 T0 = *reinterpret_cast<const float2 *>(q1b + off0 + 8);   // opacity, depth
-                    const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);
-                    const float2 T1 = *reinterpret_cast<const float2 *>(q1b + off1 + 8);
+                    const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
                     const float4 C1 = *reinterpret_cast<const float4 *>(q2b + off1);
                     float E0, E1;
                     if (FAST_EXP) { E0 = __expf(-sg0); E1 = __expf(-sg1); }
                     else { E0 = c_expf_neg_small(-sg0, sE5); E1 = c_expf_neg_small(-sg1, sE5); }
-                    const float al0 = fminf(kMaxAlpha, T0.x * E0);
-                    const float al1 = fminf(kMaxAlpha, T1.x * E1);
-                    // first entry
+                    const float al0 = fminf(kMaxAlpha, H0.w * E0);
+                    const float al1 = fminf(kMaxAlpha, H1.w * E1);
+                    // first entry: weight w = alpha T, next T = T - w
                     const wmask keep0 = cand0 & ~__ballot(al0 < kAlphaThr);
-                    const float nT0 = p.T * (1.0f - al0);
+                    const float w0 = al0 * p.T;
+                    const float nT0 = p.T - w0;
                     const wmask stop0 = keep0 & __ballot(nT0 <= kTStop);   // the splat that ends a pixel is not added
                     const wmask upd0 = keep0 & ~stop0;
                     // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
                     // colours and depths of the path, so one select on the weight replaces four
-                    const float vis0 = sel_mask_or_zero(al0 * p.T, upd0);
+                    const float vis0 = sel_mask_or_zero(w0, upd0);
                     const float Tm = sel_mask(p.T, nT0, upd0);
                     // second entry: a pixel the first one terminated takes nothing more
                     const wmask keep1 = cand1 & ~__ballot(al1 < kAlphaThr) & ~stop0;
-                    const float nT1 = Tm * (1.0f - al1);
+                    const float w1 = al1 * Tm;
+                    const float nT1 = Tm - w1;
                     const wmask stop1 = keep1 & __ballot(nT1 <= kTStop);
                     const wmask upd1 = keep1 & ~stop1;
                     DBG_ADD(3, __popcll(upd0) + __popcll(upd1));
-                    const float vis1 = sel_mask_or_zero(al1 * Tm, upd1);
+                    const float vis1 = sel_mask_or_zero(w1, upd1);
                     p.T = sel_mask(Tm, nT1, upd1);
                     p.r = fma_(C1.x, vis1, fma_(C0.x, vis0, p.r));
                     p.g = fma_(C1.y, vis1, fma_(C0.y, vis0, p.g));
                     p.b = fma_(C1.z, vis1, fma_(C0.z, vis0, p.b));
-                    p.d = fma_(T1.y, vis1, fma_(T0.y, vis0, p.d));
+                    p.d = fma_(C1.w, vis1, fma_(C0.w, vis0, p.d));
                     const wmask stopm = stop0 | stop1;
                     if (stopm) {   // rare: some pixel terminated on these splats
-                        p.px = sel_mask(p.px, kDeadPx, stopm);
-                        if (__all(p.px >= kDeadPx)) break;
+                        p.x = sel_mask(p.x, __builtin_nanf(""), stopm);
+                        if (__all(pix_dead(p))) break;
                     }
                 }
             }
-            wdone = __all(p.px >= kDeadPx);
+            wdone = __all(pix_dead(p));
         }
     }
     if (!all_done) all_done = __syncthreads_and(wdone);   // also fences the staging buffers
@@ -718,13 +744,13 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
         pixel_of(wv, lane, ox, oy);
         const int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
         const bool inside = ix < c.W && iy < c.H;
-        PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+        PixState p = pix_init(inside, ox);
         bool wdone = __all(!inside);
         const long long beg = f.tile_offset[tile];
         long long end = f.tile_offset[tile + 1];
         if (end > f.cap) end = f.cap;
         const int *ids = f.sorted_ids + beg;
-        blend_range<FAST_EXP>(f, n_gauss, tx, ty, (float)iy + 0.5f, (int)(end - beg),
+        blend_range<FAST_EXP>(f, n_gauss, tx, ty, pix_const(ox, oy), (int)(end - beg),
                               [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
         const float ED = write_pixel(o, p, inside, ix, iy, c.W);
         if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
@@ -770,9 +796,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
     int ox, oy;
     pixel_of(wv, lane, ox, oy);
     const int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
-    const float py = (float)iy + 0.5f;
+    const PixConst pc = pix_const(ox, oy);
     const bool inside = ix < c.W && iy < c.H;
-    PixState p = {1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+    PixState p = pix_init(inside, ox);
     bool wdone = __all(!inside);
 
     const long long beg = f.tile_offset[tile];
@@ -806,7 +832,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
         }
         __syncthreads();
         if (!(ablate & 1)) lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
-        if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+        if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
     } else if (n > kChunk) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
         constexpr int U = SAS_TUNE_U;
@@ -921,7 +947,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
             if (!(ablate & 1)) lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
             bool all_done = true;   // ablation (debug, SAS_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
-                all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, m,
+                all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, m,
                                                  [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
             if (all_done) break;
             b_next = b1 + 1;
@@ -934,9 +960,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
             int *out = f.sorted_ids + beg;
             sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
             __syncthreads();
-            p = PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ix + 0.5f : kDeadPx};
+            p = pix_init(inside, ox);
             wdone = __all(!inside);
-            blend_range<FAST_EXP>(f, n_gauss, tx, ty, py, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
+            blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
         }
     }
     const float ED = write_pixel(o, p, inside, ix, iy, c.W);
