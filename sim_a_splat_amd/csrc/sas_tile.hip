@@ -492,7 +492,8 @@ DEV float vgpr_const(unsigned bits)
 
 #ifdef SAS_TUNE_STATS
 // A/B builds only: [0] wave-iterations of the compositing loop, [1] of those with a candidate lane,
-// [2] candidate lanes, [3] lanes that composited, [4] staged entries, [5] queued (entry, wave) pairs
+// [2] candidate lanes, [3] lanes that composited, [4] staged entries, [5] queued (entry, block) pairs,
+// [6] / [7] wave cycles waiting at the batch barrier / inside the compositing loop
 __device__ unsigned long long g_dbg[8];
 extern "C" int sas_debug_counters(unsigned long long *out, int reset)
 {
@@ -572,9 +573,16 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     const char *q1b = reinterpret_cast<const char *>(L.q1);
     const char *q2b = reinterpret_cast<const char *>(L.q2);
     bool all_done = false;
+#ifdef SAS_TUNE_STATS
+    long long t_loop_end = 0;
+#endif
     for (int at = 0; at < count; at += 256) {
         // the previous batch is fully consumed; leave once every wave has terminated
-        if (__syncthreads_and(wdone)) { all_done = true; break; }
+        const bool every_done = __syncthreads_and(wdone);
+#ifdef SAS_TUNE_STATS
+        if (t_loop_end) DBG_ADD(6, clock64() - t_loop_end);   // [6] cycles waves waited for the slowest wave of a batch
+#endif
+        if (every_done) { all_done = true; break; }
         unsigned ment = 0u;
         if (have) ment = block_mask16(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
         // Contract T6: sigma as a polynomial in the tile-local pixel centre (x, y),
@@ -619,6 +627,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 }
             }
             const int kmax = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
+#ifdef SAS_TUNE_STATS
+            const long long t_loop = clock64();
+#endif
             DBG_ADD(5, qn[0] + qn[1] + qn[2] + qn[3]);
             if (wv == 0) DBG_ADD(4, cnt);
             // Two queue entries per trip: their record loads, sigmas and exponentials are independent
@@ -678,6 +689,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 }
             }
             wdone = __all(pix_dead(p));
+#ifdef SAS_TUNE_STATS
+            t_loop_end = clock64();
+            DBG_ADD(7, t_loop_end - t_loop);   // [7] cycles in the compositing loop
+#endif
         }
     }
     if (!all_done) all_done = __syncthreads_and(wdone);   // also fences the staging buffers
