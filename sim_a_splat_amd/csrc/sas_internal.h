@@ -82,6 +82,9 @@ void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *pe
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
                          float4 *col);
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, const SasFrame &f);
+// two views of the scene in one pass over the Gaussians (same scene, same image grid not required)
+void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams *P0, const SasFrame &f0, const SasParams *P1,
+                         const SasFrame &f1);
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f);
 struct SasSortStreams {

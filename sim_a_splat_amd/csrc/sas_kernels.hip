@@ -172,14 +172,121 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
 }
 
 // ---- k_project: T1 + T2 + tile counts ----------------------------------------------------------
-template <int DEG>
-__global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__restrict__ P, SasFrame f)
+// NV = 1: one view.  NV = 2: two views of the same scene in one pass (sas_render_batch pairs them):
+// the Gaussian's 236 bytes, its group transform and its 3-D covariance are fetched / computed once,
+// and only the camera-dependent part (projection, SH direction, record, binning) runs per view --
+// the second view's input traffic, 77 % of a projection's HBM bytes, disappears.
+struct ViewSet {
+    const SasParams *P[2];
+    SasFrame f[2];
+};
+
+// camera-dependent results of one Gaussian for one view
+struct ViewGeom {
+    bool vis;
+    int x0, x1, y0, y1;
+    float mx, my, ca, cb, ccn, thr, z, rx, ry;
+};
+
+// T1 after the camera transform: cull, EWA projection, conic, radii, tile rectangle
+DEV void project_view(const SasCam &c, const float *cov, float op, float x, float y, float z, ViewGeom &g)
 {
-    const SasCam c = P->cam;   // wave-uniform: scalar loads
+    float cc3[6];
+    rot_sym3(c.R, cov, cc3);
+
+    const float rz = 1.0f / z;
+    const float rz2 = rz * rz;
+    const float tx = z * fminf(c.lim_x_pos, fmaxf(-c.lim_x_neg, x * rz));
+    const float ty = z * fminf(c.lim_y_pos, fmaxf(-c.lim_y_neg, y * rz));
+    const float ja = c.fx * rz, jb = -((c.fx * tx) * rz2);
+    const float jc = c.fy * rz, jd = -((c.fy * ty) * rz2);
+    const float t00 = fma_(jb, cc3[2], ja * cc3[0]);
+    const float t01 = fma_(jb, cc3[4], ja * cc3[1]);
+    const float t02 = fma_(jb, cc3[5], ja * cc3[2]);
+    const float t11 = fma_(jd, cc3[4], jc * cc3[3]);
+    const float t12 = fma_(jd, cc3[5], jc * cc3[4]);
+    float c00 = fma_(t02, jb, t00 * ja);
+    const float c01 = fma_(t02, jd, t01 * jc);
+    float c11 = fma_(t12, jd, t11 * jc);
+    const float mx = fma_(c.fx, x * rz, c.cx);
+    const float my = fma_(c.fy, y * rz, c.cy);
+    c00 += kEps2d;
+    c11 += kEps2d;
+    const float det = fma_(c00, c11, -(c01 * c01));
+    if (!(det > 0.0f)) return;
+    const float inv_det = 1.0f / det;
+    const float ca = c11 * inv_det, cb = -c01 * inv_det, ccn = c00 * inv_det;
+    const float lnq = c_logf(op / kAlphaThr);
+    const float extent = fminf(3.33f, sqrtf(2.0f * lnq));
+    const float b = 0.5f * (c00 + c11);
+    const float tmp = sqrtf(fmaxf(0.01f, fma_(b, b, -det)));
+    const float v1 = b + tmp;
+    const float r1 = extent * sqrtf(v1);
+    const float rx = ceilf(fminf(extent * sqrtf(c00), r1));
+    const float ry = ceilf(fminf(extent * sqrtf(c11), r1));
+    bool keep = !(rx <= 0.0f && ry <= 0.0f);
+    keep = keep && !(mx + rx <= 0.0f || mx - rx >= c.Wf || my + ry <= 0.0f || my - ry >= c.Hf);
+    keep = keep && rx > 0.0f && ry > 0.0f;
+    if (!keep) return;
+    g.vis = true;
+    // T3 tile rectangle
+    const float ts = (float)SAS_TILE;
+    const float trx = rx / ts, try_ = ry / ts;
+    const float ttx = mx / ts, tty = my / ts;
+    const float twf = (float)c.tw, thf = (float)c.th;
+    g.x0 = (int)fminf(fmaxf(floorf(ttx - trx), 0.0f), twf);
+    g.x1 = (int)fminf(fmaxf(ceilf(ttx + trx), 0.0f), twf);
+    g.y0 = (int)fminf(fmaxf(floorf(tty - try_), 0.0f), thf);
+    g.y1 = (int)fminf(fmaxf(ceilf(tty + try_), 0.0f), thf);
+    g.mx = mx; g.my = my; g.ca = ca; g.cb = cb; g.ccn = ccn; g.z = z; g.rx = rx; g.ry = ry;
+    // conservative skip threshold for the blend stage: alpha >= 1/255 implies
+    // sigma <= ln(255 op) + rounding; 1e-3 is > 100x the worst rounding.
+    g.thr = lnq + 1e-3f;
+}
+
+// per-tile counts of one view: LDS histogram over the workgroup's window, one global atomic per
+// touched tile; then the workgroup's visible count.  Reached by all 256 threads.
+DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, int *s_hist, int *s_nvis)
+{
+    const bool vis = g.vis;
+    const int x0 = g.x0, x1 = g.x1, y0 = g.y0, y1 = g.y1;
+    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
+    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
+    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    if (w.fits) {
+        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
+        __syncthreads();
+        if (in_win)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
+        __syncthreads();
+        for (int b = threadIdx.x; b < w.area; b += 256) {
+            const int cnt = s_hist[b];
+            if (cnt) atomicAdd(&f.tile_count[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww], cnt);
+        }
+    } else if (threadIdx.x == 0 && w.area > 0) {
+        atomicAdd(&f.stats[5], 1u);
+    }
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
+                  [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
+    // visible count: one plain store per workgroup (a same-address atomic per wave would
+    // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
+    if (threadIdx.x == 0) *s_nvis = 0;
+    __syncthreads();
+    const unsigned long long vb = __ballot(vis);
+    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(s_nvis, (int)__popcll(vb));
+    __syncthreads();
+    if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = *s_nvis;
+}
+
+template <int DEG, int NV>
+__global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
+{
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < s.n;
-    bool vis = false;
-    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    ViewGeom g[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { g[v].vis = false; g[v].x0 = g[v].x1 = g[v].y0 = g[v].y1 = 0; }
     if (in_range) {
         // the scene is streamed once per frame: non-temporal loads keep it from evicting the
         // records / keys that the tile kernels (of this and the other in-flight frame) re-read
@@ -196,12 +303,20 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__
             float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
             m[0] = mg0; m[1] = mg1; m[2] = mg2;
         }
-        const float x = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);
-        const float y = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
-        const float z = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
-        bool ok = !(z < kNear || z > kFar);
-        ok = ok && !(op < kAlphaThr);   // opacity cull moved up: it has no side effect before the det test
-        if (ok) {
+        float cx[NV], cy[NV], cz[NV];
+        bool ok[NV], any_ok = false;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const SasCam &c = vs.P[v]->cam;   // wave-uniform: scalar loads
+            cx[v] = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);
+            cy[v] = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
+            cz[v] = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
+            ok[v] = !(cz[v] < kNear || cz[v] > kFar);
+            ok[v] = ok[v] && !(op < kAlphaThr);   // opacity cull moved up: it has no side effect before the det test
+            any_ok = any_ok || ok[v];
+        }
+        if (any_ok) {
+            // 3-D covariance in the world (group) frame: camera-independent
             float cov[6];
             if (!s.cov_mode) {
                 float qw = a1.x, qx = a1.y, qy = a1.z, qz = a1.w;
@@ -247,113 +362,50 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, const SasParams *__
                     for (int k = 0; k < 6; ++k) cov[k] = c2[k];
                 }
             }
-            float cc3[6];
-            rot_sym3(c.R, cov, cc3);
-
-            const float rz = 1.0f / z;
-            const float rz2 = rz * rz;
-            const float tx = z * fminf(c.lim_x_pos, fmaxf(-c.lim_x_neg, x * rz));
-            const float ty = z * fminf(c.lim_y_pos, fmaxf(-c.lim_y_neg, y * rz));
-            const float ja = c.fx * rz, jb = -((c.fx * tx) * rz2);
-            const float jc = c.fy * rz, jd = -((c.fy * ty) * rz2);
-            const float t00 = fma_(jb, cc3[2], ja * cc3[0]);
-            const float t01 = fma_(jb, cc3[4], ja * cc3[1]);
-            const float t02 = fma_(jb, cc3[5], ja * cc3[2]);
-            const float t11 = fma_(jd, cc3[4], jc * cc3[3]);
-            const float t12 = fma_(jd, cc3[5], jc * cc3[4]);
-            float c00 = fma_(t02, jb, t00 * ja);
-            const float c01 = fma_(t02, jd, t01 * jc);
-            float c11 = fma_(t12, jd, t11 * jc);
-            const float mx = fma_(c.fx, x * rz, c.cx);
-            const float my = fma_(c.fy, y * rz, c.cy);
-            c00 += kEps2d;
-            c11 += kEps2d;
-            const float det = fma_(c00, c11, -(c01 * c01));
-            if (det > 0.0f) {
-                const float inv_det = 1.0f / det;
-                const float ca = c11 * inv_det, cb = -c01 * inv_det, ccn = c00 * inv_det;
-                const float lnq = c_logf(op / kAlphaThr);
-                const float extent = fminf(3.33f, sqrtf(2.0f * lnq));
-                const float b = 0.5f * (c00 + c11);
-                const float tmp = sqrtf(fmaxf(0.01f, fma_(b, b, -det)));
-                const float v1 = b + tmp;
-                const float r1 = extent * sqrtf(v1);
-                const float rx = ceilf(fminf(extent * sqrtf(c00), r1));
-                const float ry = ceilf(fminf(extent * sqrtf(c11), r1));
-                bool keep = !(rx <= 0.0f && ry <= 0.0f);
-                keep = keep && !(mx + rx <= 0.0f || mx - rx >= c.Wf || my + ry <= 0.0f || my - ry >= c.Hf);
-                keep = keep && rx > 0.0f && ry > 0.0f;
-                if (keep) {
-                    vis = true;
-                    // T3 tile rectangle
-                    const float ts = (float)SAS_TILE;
-                    const float trx = rx / ts, try_ = ry / ts;
-                    const float ttx = mx / ts, tty = my / ts;
-                    const float twf = (float)c.tw, thf = (float)c.th;
-                    x0 = (int)fminf(fmaxf(floorf(ttx - trx), 0.0f), twf);
-                    x1 = (int)fminf(fmaxf(ceilf(ttx + trx), 0.0f), twf);
-                    y0 = (int)fminf(fmaxf(floorf(tty - try_), 0.0f), thf);
-                    y1 = (int)fminf(fmaxf(ceilf(tty + try_), 0.0f), thf);
-                    // colour
+            bool any_vis = false;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (ok[v]) project_view(vs.P[v]->cam, cov, op, cx[v], cy[v], cz[v], g[v]);
+                any_vis = any_vis || g[v].vis;
+            }
+            if (any_vis) {
+                // colour: the coefficient planes are fetched once for all views
+                constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
+                constexpr int PL = (KF + 3) / 4;
+                float sh[PL * 4];
+#pragma unroll
+                for (int p = 0; p < PL; ++p) {
+                    const float4 q = nt_load(s.col + (int64_t)p * s.n_pad + i);
+                    sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    if (!g[v].vis) continue;
+                    const SasCam &c = vs.P[v]->cam;
                     float rgb[3];
                     if constexpr (DEG >= 0) {
-                        constexpr int KF = 3 * (DEG + 1) * (DEG + 1);
-                        constexpr int PL = (KF + 3) / 4;
-                        float sh[PL * 4];
-#pragma unroll
-                        for (int p = 0; p < PL; ++p) {
-                            const float4 v = nt_load(s.col + (int64_t)p * s.n_pad + i);
-                            sh[4 * p] = v.x; sh[4 * p + 1] = v.y; sh[4 * p + 2] = v.z; sh[4 * p + 3] = v.w;
-                        }
                         sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
                     } else {
-                        const float4 v = nt_load(s.col + i);
-                        rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
+                        rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
                     }
-                    // conservative skip threshold for the blend stage: alpha >= 1/255 implies
-                    // sigma <= ln(255 op) + rounding; 1e-3 is > 100x the worst rounding.
-                    const float thr = lnq + 1e-3f;
-                    f.rec[3 * i + 0] = make_float4(mx, my, ca, cb);
-                    f.rec[3 * i + 1] = make_float4(ccn, op, thr, z);
+                    const SasFrame &f = vs.f[v];
+                    f.rec[3 * i + 0] = make_float4(g[v].mx, g[v].my, g[v].ca, g[v].cb);
+                    f.rec[3 * i + 1] = make_float4(g[v].ccn, op, g[v].thr, g[v].z);
                     f.rec[3 * i + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
-                    f.info[i] = make_uint4((unsigned)x0 | ((unsigned)x1 << 16), (unsigned)y0 | ((unsigned)y1 << 16),
-                                           __float_as_uint(z), (unsigned)(int)rx | ((unsigned)(int)ry << 16));
+                    f.info[i] = make_uint4((unsigned)g[v].x0 | ((unsigned)g[v].x1 << 16), (unsigned)g[v].y0 | ((unsigned)g[v].y1 << 16),
+                                           __float_as_uint(g[v].z), (unsigned)(int)g[v].rx | ((unsigned)(int)g[v].ry << 16));
                 }
             }
         }
-        if (!vis) f.info[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (!g[v].vis) vs.f[v].info[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    // per-tile counts: LDS histogram over the workgroup's window, one global atomic per touched tile
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
-    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
-    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
-    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
-    if (w.fits) {
-        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
-        __syncthreads();
-        if (in_win)
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
-        __syncthreads();
-        for (int b = threadIdx.x; b < w.area; b += 256) {
-            const int cnt = s_hist[b];
-            if (cnt) atomicAdd(&f.tile_count[(w.Y0 + b / w.ww) * c.tw + w.X0 + b % w.ww], cnt);
-        }
-    } else if (threadIdx.x == 0 && w.area > 0) {
-        atomicAdd(&f.stats[5], 1u);
-    }
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, c.tw, 0u, 0u,
-                  [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
-    // visible count: one plain store per workgroup (a same-address atomic per wave would
-    // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
     __shared__ int s_nvis;
-    if (threadIdx.x == 0) s_nvis = 0;
-    __syncthreads();
-    const unsigned long long vb = __ballot(vis);
-    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis, (int)__popcll(vb));
-    __syncthreads();
-    if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = s_nvis;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.P[v]->cam.tw, g[v], s_win, s_hist, &s_nvis);
 }
 
 // ---- k_scan: exclusive scan over tiles (workgroup 0) + tile order (workgroup 1) -------------------
@@ -539,17 +591,36 @@ void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *pe
                        coeff_floats, planes, gid, g0, g1, g2, col);
 }
 
+template <int NV>
+static void launch_project(hipStream_t st, const SasScene &s, const ViewSet &vs)
+{
+    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    switch (s.sh_degree) {
+        case 0: hipLaunchKernelGGL((k_project<0, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
+        case 1: hipLaunchKernelGGL((k_project<1, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
+        case 2: hipLaunchKernelGGL((k_project<2, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
+        case 3: hipLaunchKernelGGL((k_project<3, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
+        default: hipLaunchKernelGGL((k_project<-1, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
+    }
+}
+
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, const SasFrame &f)
 {
     if (s.n <= 0) return;
-    const unsigned grid = (unsigned)((s.n + 255) / 256);
-    switch (s.sh_degree) {
-        case 0: hipLaunchKernelGGL(k_project<0>, dim3(grid), dim3(256), 0, st, s, P, f); break;
-        case 1: hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, st, s, P, f); break;
-        case 2: hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, st, s, P, f); break;
-        case 3: hipLaunchKernelGGL(k_project<3>, dim3(grid), dim3(256), 0, st, s, P, f); break;
-        default: hipLaunchKernelGGL(k_project<-1>, dim3(grid), dim3(256), 0, st, s, P, f); break;
-    }
+    ViewSet vs;
+    vs.P[0] = P; vs.P[1] = P;
+    vs.f[0] = f; vs.f[1] = f;
+    launch_project<1>(st, s, vs);
+}
+
+void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams *P0, const SasFrame &f0, const SasParams *P1,
+                         const SasFrame &f1)
+{
+    if (s.n <= 0) return;
+    ViewSet vs;
+    vs.P[0] = P0; vs.P[1] = P1;
+    vs.f[0] = f0; vs.f[1] = f1;
+    launch_project<2>(st, s, vs);
 }
 
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)
