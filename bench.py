@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4, help="steps between tile-kernel timing samples")
+    ap.add_argument("--views-per-step", type=int, default=2, choices=(1, 2),
+                    help="independent views each GPU renders per step; 2 = a view pair (one projection pass for both)")
     a = ap.parse_args()
 
     rank, world, local_rank = sdist.init_from_env()
@@ -93,22 +96,28 @@ def main():
 
     W, H = 1920, 1080
     scene = make_scene(a.gaussians, seed=3, log_scale_mean=float(np.log(0.006)))
-    cam = ring_camera(W, H, 1000.0, yaw_deg=45.0 * rank)   # one independent view per GPU
+    # independent views: GPU g renders the ring cameras at yaw 45 g (and 45 g + 180 for the second view of a pair)
+    VPS = a.views_per_step
+    cams = [ring_camera(W, H, 1000.0, yaw_deg=45.0 * rank + 180.0 * v) for v in range(VPS)]
+    cam = cams[0]
+    Vs, Ks = np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams])
     r = Rasterizer(dev)
     r.upload(scene.means, scene.opacities, scene.sh, quats=scene.quats, scales=scene.scales, sh_degree=3)
-    # every rank writes the float32 frame (the metric's output) and its uint8 twin; the gather moves
-    # the uint8 frame, the format Gym observations are exchanged in (splat_env_wrapper.py:135-137):
+    # every rank writes the float32 frames (the metric's output) and their uint8 twins; the gather moves
+    # the uint8 frames, the format Gym observations are exchanged in (splat_env_wrapper.py:135-137):
     # 6.2 MB instead of 24.9 MB per frame keeps the xGMI transfer shorter than a frame
-    bufs = [{"rgb": torch.empty((H, W, 3), dtype=torch.float32, device=dev),
-             "rgb8": torch.empty((H, W, 3), dtype=torch.uint8, device=dev)} for _ in range(3)]
+    bufs = [{"rgb": torch.empty((VPS, H, W, 3), dtype=torch.float32, device=dev),
+             "rgb8": torch.empty((VPS, H, W, 3), dtype=torch.uint8, device=dev)} for _ in range(3)]
     gather = sdist.FrameGather(world, rank)
 
     def step(i, timing):
         out = bufs[i % 3]
-        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=out, block=False,
-                 time_tiles=timing)
-        # After render(i) returns, the current stream is ordered behind frame i-1 (C ABI contract):
-        # gather that one, so the xGMI transfer of frame i-1 overlaps the rendering of frame i.
+        # one C-ABI call per step: the step's views go through the frame slots back to back, a pair of
+        # views shares one pass over the scene (sas_render_batch)
+        r.render_batch(Vs, Ks, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=out, block=False,
+                       time_tiles=timing)
+        # After the call returns, the current stream is ordered behind every view of step i-1 (C ABI
+        # contract): gather those, so the xGMI transfer of step i-1 overlaps the rendering of step i.
         if world > 1 and i > 0:
             gather.start(bufs[(i - 1) % 3]["rgb8"])
 
@@ -128,7 +137,9 @@ def main():
     r.stage_time_means(reset=True)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(i, True)     # SAS_TIME_TILES: HIP events around the dominant kernel, frames keep pipelining
+        # SAS_TIME_TILES on every TIME_EVERY-th step: HIP events around the dominant kernel of that
+        # step's frames (on the kernel's own stream), the frames keep pipelining
+        step(i, i % a.time_every == 0)
     sync(a.steps - 1)
     elapsed = time.perf_counter() - t0
     means, timed_frames = r.stage_time_means(reset=True)
@@ -137,20 +148,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = r.stats()
+    # intersections / visible Gaussians of each view of the step (the mean enters the byte counts)
+    per_view = []
+    for c_ in cams:
+        r.render(c_.viewmat, c_.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out={"rgb": bufs[0]["rgb"][0]})
+        per_view.append(r.stats())
+    st = {k: int(round(np.mean([pv[k] for pv in per_view]))) for k in ("n_visible", "n_isect")}
 
     # per-stage breakdown of an isolated frame (nothing else on the GPU): 10 frames with events at
     # every stage boundary, after the timed region
     stage = {}
     for i in range(10):
-        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=bufs[0], timing=True)
+        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"),
+                 out={k: v[0] for k, v in bufs[0].items()}, timing=True)
         for k, v in r.stage_times().items():
             stage.setdefault(k, []).append(v)
     blend_s = tile_ms * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        fps = world * a.steps / elapsed
+        fps = world * VPS * a.steps / elapsed
         achieved = tile_kernel_bytes(st["n_isect"], W, H) / blend_s / 1e9
         frame_bytes = algorithmic_bytes(scene.n, st["n_visible"], st["n_isect"], W, H)
         line = {
@@ -159,16 +176,18 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: 1M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, "
-                                   "fx=fy=1000, one view per GPU, float32 RGB + uint8 RGB out",
+                                   f"fx=fy=1000, {VPS} independent view(s) per GPU per step"
+                                   + (" (a view pair shares one projection pass)" if VPS == 2 else "")
+                                   + ", float32 RGB + uint8 RGB out per view",
                        "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
-                       "views_per_step": world, "parallelism": f"views{world}",
+                       "views_per_step": world * VPS, "parallelism": f"views{world}x{VPS}",
                        "gather": "uint8 frames to rank 0 (RCCL), one frame behind the renderer" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy"),
                          "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames,
                          "kernel_ms_isolated_frame": float(np.mean(stage["blend"])),
-                         "frame_algorithmic_GBps": frame_bytes / (elapsed / a.steps) / 1e9,
-                         "frame_frac": frame_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS,
+                         "frame_algorithmic_GBps": frame_bytes / (elapsed / a.steps / VPS) / 1e9,
+                         "frame_frac": frame_bytes / (elapsed / a.steps / VPS) / 1e9 / HBM_PEAK_GBPS,
                          "isolated_frame_stage_ms": {k: float(np.mean(v)) for k, v in stage.items()}},
         }
         if world == 1 and not a.no_cpu_baseline:

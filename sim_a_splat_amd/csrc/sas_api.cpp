@@ -57,6 +57,7 @@ struct Slot {
     hipStream_t fs = nullptr;
     SasSortStreams sort_streams{};
     hipEvent_t start = nullptr, done = nullptr, front_done = nullptr;
+    hipEvent_t pair_ev = nullptr;   // leader of a view pair: both projections are done
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
     unsigned *stats_host = nullptr;  // pinned, 8 words
     Scratch scr;
@@ -95,7 +96,7 @@ struct sas_ctx {
     std::vector<float> group_host;
     // frames
     Slot slots[kMaxSlots];
-    int n_slots = 2;     // frames that may be in flight (SAS_SLOTS=1..4 overrides the default of 2)
+    int n_slots = 4;     // frames that may be enqueued (SAS_SLOTS=1..4); run_depth of them execute at once
     int head = 0;        // oldest busy slot
     int inflight = 0;
     int last_slot = 0;   // most recently enqueued (parity hooks)
@@ -110,7 +111,8 @@ struct sas_ctx {
     // Frames that may EXECUTE at once (<= n_slots).  With more slots than that, the extra frames
     // are queued on the GPU behind done events, so no host round trip sits between a frame
     // finishing and the next one starting.
-    int run_depth = 0;   // 0: same as n_slots
+    int run_depth = 2;   // SAS_RUN_DEPTH; 0: same as n_slots
+    bool pair_views = true;   // sas_render_batch projects two views per pass over the scene (SAS_PAIR=0 disables)
     uint64_t scene_version = 0;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
@@ -259,21 +261,41 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
     return f;
 }
 
+// Roles of a slot in a view pair (sas_render_batch): the LEADER's stream uploads both parameter
+// blocks, clears both counter blocks and runs one two-view projection; the FOLLOWER's stream waits
+// for it and continues with its own binning and tiles.
+enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
+
+size_t counter_bytes(int tiles)
+{
+    const size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
+    return (cbytes + 15) & ~(size_t)15;
+}
+
 // The frame's work on stream `st`: parameter block, counters, the five stages, stats read-back.
-int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t st_tile = nullptr)
+int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t st_tile = nullptr, int role = ROLE_SINGLE,
+                 Slot *partner = nullptr)
 {
     const RenderArgs &a = sl.args;
     const SasCam &cam = sl.cam;
     const int tiles = cam.tw * cam.th;
     Scratch &q = sl.scr;
-    size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
-    cbytes = (cbytes + 15) & ~(size_t)15;
     SasFrame f = frame_of(c, q, tiles);
     const SasParams *P = (const SasParams *)sl.params_dev.p;
-    HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
-    HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, cbytes, st));
-    sas_launch_project(st, c->scene, P, f);
+    if (role != ROLE_FOLLOWER) {
+        HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+        if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
+        HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, counter_bytes(tiles), st));
+    }
+    if (role == ROLE_LEADER) {
+        const int ptiles = partner->cam.tw * partner->cam.th;
+        HIP_TRY(c, hipMemcpyAsync(partner->params_dev.p, partner->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(partner->scr.counters.p, 0, counter_bytes(ptiles), st));
+        sas_launch_project2(st, c->scene, P, f, (const SasParams *)partner->params_dev.p, frame_of(c, partner->scr, ptiles));
+        HIP_TRY(c, hipEventRecord(sl.pair_ev, st));
+    } else if (role == ROLE_SINGLE) {
+        sas_launch_project(st, c->scene, P, f);
+    }
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
     sas_launch_scan(st, tiles, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
@@ -300,11 +322,8 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
     return SAS_OK;
 }
 
-// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
-// Untimed frames replay a hipGraph captured once per (slot, image size, flags, scene, scratch):
-// one launch instead of ~25 runtime calls, which otherwise cost more host time than the frame
-// takes on the GPU.
-int enqueue_frame(sas_ctx *c, Slot &sl)
+// Camera constants, scratch sizes and the host copy of the parameter block of the slot's frame.
+int prepare_frame(sas_ctx *c, Slot &sl)
 {
     const RenderArgs &a = sl.args;
     make_cam(a.viewmat, a.K, a.W, a.H, sl.cam);
@@ -313,8 +332,6 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     const int64_t n = c->scene.n;
     Scratch &q = sl.scr;
     int rc;
-    size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
-    cbytes = (cbytes + 15) & ~(size_t)15;
     if (q.cap == 0) {
         long long want = 4 * (long long)n;
         if (want < (1ll << 20)) want = 1ll << 20;
@@ -323,7 +340,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     if ((rc = ensure(c, q.rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(4 * tiles + 16)))) return rc;
-    if ((rc = ensure(c, q.counters, cbytes))) return rc;
+    if ((rc = ensure(c, q.counters, counter_bytes(tiles)))) return rc;
     if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
     if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
@@ -336,14 +353,29 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
     hp.out.points = a.points; hp.out.mask = a.mask;
     hp.out.max_depth = a.max_depth; hp.out.use_max_depth = a.use_max_depth ? 1 : 0;
+    return SAS_OK;
+}
+
+// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
+// Untimed single frames replay a hipGraph captured once per (slot, image size, flags, scene,
+// scratch): one launch instead of ~25 runtime calls.  The two frames of a view pair (role, partner;
+// both prepared by the caller) are enqueued eagerly.
+int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = nullptr)
+{
+    const RenderArgs &a = sl.args;
+    int rc;
+    if (role == ROLE_SINGLE && (rc = prepare_frame(c, sl))) return rc;
+    const int64_t n = c->scene.n;
+    Scratch &q = sl.scr;
 
     const bool timing = (a.flags & SAS_TIMING) != 0;
-    const bool piped = c->pipeline && !timing && !(a.flags & SAS_FULL_SORT);
+    const bool piped = c->pipeline && !timing && !(a.flags & SAS_FULL_SORT) && role == ROLE_SINGLE;
     hipStream_t st = piped ? c->s_front : sl.fs;
     hipStream_t st_end = piped ? c->s_tile : sl.fs;
     // start after whatever the caller has enqueued on its stream so far
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
     if (c->run_depth > 0 && c->run_depth < c->n_slots) {
         const int me = (int)(&sl - c->slots);
         Slot &gate = c->slots[(me + c->n_slots - c->run_depth) % c->n_slots];   // frame j - run_depth
@@ -351,7 +383,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
     }
     bool launched = false;
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
-    if (!timing && !ttiles && !piped && c->use_graphs) {
+    if (!timing && !ttiles && !piped && role == ROLE_SINGLE && c->use_graphs) {
         Slot::GraphKey key;
         key.W = a.W; key.H = a.H;
         key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
@@ -384,7 +416,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl)
         }
     }
     if (!launched) {
-        rc = enqueue_body(c, sl, st, timing, st_end);
+        rc = enqueue_body(c, sl, st, timing, st_end, role, partner);
         if (rc) return rc;
         HIP_TRY(c, hipGetLastError());
     }
@@ -479,6 +511,7 @@ int sas_create(int device, sas_ctx **out)
     }
     if (const char *e = getenv("SAS_PIPELINE")) c->pipeline = atoi(e);
     if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
+    if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0;
     if (c->pipeline) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -493,6 +526,7 @@ int sas_create(int device, sas_ctx **out)
         ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.pair_ev, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         for (auto &sd : sl.sort_streams.side) ok = ok && hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.sort_streams.fork, hipEventDisableTiming) == hipSuccess;
@@ -528,6 +562,7 @@ int sas_destroy(sas_ctx *c)
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.front_done) (void)hipEventDestroy(sl.front_done);
+        if (sl.pair_ev) (void)hipEventDestroy(sl.pair_ev);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
@@ -659,54 +694,96 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
     return SAS_OK;
 }
 
-static int render_impl(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
-                       unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, float *points,
-                       uint8_t *mask, const float *max_depth, void *stream)
+struct ViewCall {
+    const float *viewmat, *K;
+    float *rgb, *alpha, *depth;
+    uint8_t *rgb8;
+    float *points;
+    uint8_t *mask;
+};
+
+static int check_view(sas_ctx *c, const ViewCall &v, int width, int height)
 {
-    if (!c) return SAS_ERR_INVALID;
     if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "sas_render before sas_scene_upload");
-    if (!viewmat || !K) return fail(c, SAS_ERR_INVALID, "viewmat and K are required");
+    if (!v.viewmat || !v.K) return fail(c, SAS_ERR_INVALID, "viewmat and K are required");
     if (width <= 0 || height <= 0 || width > 65535 * SAS_TILE || height > 65535 * SAS_TILE)
         return fail(c, SAS_ERR_INVALID, "bad image size %dx%d", width, height);
-    if (!(K[0] > 0.0f) || !(K[4] > 0.0f)) return fail(c, SAS_ERR_INVALID, "focal lengths must be positive");
-    if ((points || mask) && !depth) return fail(c, SAS_ERR_INVALID, "points / mask need the depth output");
+    if (!(v.K[0] > 0.0f) || !(v.K[4] > 0.0f)) return fail(c, SAS_ERR_INVALID, "focal lengths must be positive");
+    if ((v.points || v.mask) && !v.depth) return fail(c, SAS_ERR_INVALID, "points / mask need the depth output");
+    return SAS_OK;
+}
+
+static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, const float *background, unsigned flags,
+                      const float *max_depth, hipStream_t st)
+{
+    memcpy(a.viewmat, v.viewmat, sizeof(a.viewmat));
+    memcpy(a.K, v.K, sizeof(a.K));
+    for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
+    a.W = width; a.H = height; a.flags = flags;
+    a.rgb = v.rgb; a.alpha = v.alpha; a.depth = v.depth; a.rgb8 = v.rgb8;
+    a.points = v.points; a.mask = v.mask;
+    a.use_max_depth = max_depth != nullptr;
+    a.max_depth = max_depth ? *max_depth : 0.0f;
+    a.stream = st;
+    a.valid = true;
+}
+
+// One view (n == 1) or a pair of views that share one projection pass (n == 2).
+static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int height, const float *background,
+                        unsigned flags, const float *max_depth, void *stream)
+{
+    if (!c) return SAS_ERR_INVALID;
+    for (int k = 0; k < n; ++k) {
+        const int rc = check_view(c, views[k], width, height);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->inflight > 0 && (st != c->stream || (flags & SAS_TIMING))) {
         int rc = complete_all(c);   // one caller stream at a time; timed frames run alone
         if (rc) return rc;
     }
-    if (c->inflight == c->n_slots) {
+    while (c->inflight > c->n_slots - n) {
         int rc = complete_oldest(c);
         if (rc) return rc;
     }
     c->stream = st;
-    const int si = (c->head + c->inflight) % c->n_slots;
-    Slot &sl = c->slots[si];
-    RenderArgs &a = sl.args;
-    memcpy(a.viewmat, viewmat, sizeof(a.viewmat));
-    memcpy(a.K, K, sizeof(a.K));
-    for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
-    a.W = width; a.H = height; a.flags = flags;
-    a.rgb = rgb; a.alpha = alpha; a.depth = depth; a.rgb8 = rgb8;
-    a.points = points; a.mask = mask;
-    a.use_max_depth = max_depth != nullptr;
-    a.max_depth = max_depth ? *max_depth : 0.0f;
-    a.stream = st;
-    a.valid = true;
-    int rc = enqueue_frame(c, sl);
-    if (rc) return rc;
-    // Work the caller enqueues on `stream` from now on is ordered behind the PREVIOUS frame (a
-    // stream wait, no host synchronisation): a consumer can run one frame behind the renderer
-    // while this frame overlaps the previous one on the GPU.
-    if (c->inflight > 0) {
-        Slot &prev = c->slots[(si + c->n_slots - 1) % c->n_slots];
-        if (prev.busy) HIP_TRY(c, hipStreamWaitEvent(st, prev.done, 0));
+    Slot *sl[2] = {nullptr, nullptr};
+    for (int k = 0; k < n; ++k) {
+        sl[k] = &c->slots[(c->head + c->inflight + k) % c->n_slots];
+        fill_args(sl[k]->args, views[k], width, height, background, flags, max_depth, st);
     }
-    c->inflight++;
-    c->last_slot = si;
+    if (n == 2) {
+        for (int k = 0; k < 2; ++k) {
+            const int rc = prepare_frame(c, *sl[k]);
+            if (rc) return rc;
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        const int role = n == 1 ? ROLE_SINGLE : (k == 0 ? ROLE_LEADER : ROLE_FOLLOWER);
+        int rc = enqueue_frame(c, *sl[k], role, n == 2 ? sl[1 - k] : nullptr);
+        if (rc) return rc;
+        // Work the caller enqueues on `stream` from now on is ordered behind the PREVIOUS frame (a
+        // stream wait, no host synchronisation): a consumer can run one frame behind the renderer
+        // while this frame overlaps the previous one on the GPU.
+        if (c->inflight > 0) {
+            const int si = (int)(sl[k] - c->slots);
+            Slot &prev = c->slots[(si + c->n_slots - 1) % c->n_slots];
+            if (prev.busy) HIP_TRY(c, hipStreamWaitEvent(st, prev.done, 0));
+        }
+        c->inflight++;
+        c->last_slot = (int)(sl[k] - c->slots);
+    }
     if (flags & SAS_ASYNC) return SAS_OK;
     return complete_all(c);
+}
+
+static int render_impl(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
+                       unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8, float *points,
+                       uint8_t *mask, const float *max_depth, void *stream)
+{
+    const ViewCall v = {viewmat, K, rgb, alpha, depth, rgb8, points, mask};
+    return render_views(c, &v, 1, width, height, background, flags, max_depth, stream);
 }
 
 int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
@@ -731,11 +808,19 @@ int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float
     if (!c) return SAS_ERR_INVALID;
     if (n_views < 0 || (n_views > 0 && (!viewmats || !Ks))) return fail(c, SAS_ERR_INVALID, "bad view batch");
     const size_t px = (size_t)width * (size_t)height;
-    for (int v = 0; v < n_views; ++v) {
-        int rc = sas_render(c, viewmats + 16 * v, Ks + 9 * v, width, height, background, flags | SAS_ASYNC,
-                            rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
-                            depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, stream);
+    auto view = [&](int v) {
+        return ViewCall{viewmats + 16 * v, Ks + 9 * v, rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
+                        depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, nullptr, nullptr};
+    };
+    // Views go through the frame slots two at a time: one pass over the scene projects both
+    // (timed and full-sort frames keep to one view per pass).
+    const bool pair = c->pair_views && c->n_slots >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
+    for (int v = 0; v < n_views;) {
+        const int n = (pair && v + 1 < n_views) ? 2 : 1;
+        const ViewCall vc[2] = {view(v), view(n == 2 ? v + 1 : v)};
+        int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream);
         if (rc) return rc;
+        v += n;
     }
     if (flags & SAS_ASYNC) return SAS_OK;
     return sas_wait(c);

@@ -196,9 +196,12 @@ class Rasterizer:
 
     def render_batch(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
                      background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb",),
-                     depth_fill_max: bool = False) -> Dict[str, torch.Tensor]:
+                     depth_fill_max: bool = False, block: bool = True, time_tiles: bool = False,
+                     out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Render C same-sized views in one C-ABI call: ``viewmats [C,4,4]``, ``Ks [C,3,3]`` ->
-        tensors ``[C,H,W,...]`` (the per-camera loop of the reference, splat_env_wrapper.py:147-158)."""
+        tensors ``[C,H,W,...]`` (the per-camera loop of the reference, splat_env_wrapper.py:147-158).
+        Views are projected two per pass over the scene.  ``block=False`` only enqueues (results valid
+        after ``wait()``); ``out`` supplies the ``[C,H,W,...]`` output tensors."""
         C = int(np.asarray(viewmats).shape[0]) if not isinstance(viewmats, torch.Tensor) else int(viewmats.shape[0])
         V = self._host_f32(viewmats, 16 * C)
         Kc = self._host_f32(Ks, 9 * C)
@@ -208,15 +211,21 @@ class Rasterizer:
         ptrs = {"rgb": None, "alpha": None, "depth": None, "rgb8": None}
         for k in want:
             ch, dt = self._SHAPES[k]
-            res[k] = torch.empty((C, H, W, ch), dtype=dt, device=self.device)
-            ptrs[k] = res[k].data_ptr()
-        flags = _capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0
+            t = out.get(k) if out is not None else None
+            if t is None:
+                t = torch.empty((C, H, W, ch), dtype=dt, device=self.device)
+            elif t.shape != (C, H, W, ch) or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"out[{k!r}] must be a contiguous {dt} tensor {(C, H, W, ch)} on {self.device}")
+            res[k] = t
+            ptrs[k] = t.data_ptr()
+        flags = (_capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0) | (0 if block else _capi.SAS_ASYNC) | \
+                (_capi.SAS_TIME_TILES if time_tiles else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self._L.sas_render_batch(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
                                       ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
         if rc != 0:
             self._check(rc, "sas_render_batch")
-        self._keep = []
+        self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
     def wait(self) -> None:

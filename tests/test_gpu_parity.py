@@ -329,6 +329,38 @@ def test_config4_eight_poses_uint8_batched(rasterizer):
         assert np.array_equal(got8[v], ref["rgb8"]) and np.array_equal(got[v], ref["rgb"])
 
 
+def test_view_pairs_equal_single_views(rasterizer):
+    """sas_render_batch projects two views per pass over the scene: every output of every view of an
+    odd-sized batch (pairs + one single), one of them looking away from the scene, equals the
+    one-view-at-a-time render; an asynchronous batch keeps the stream-ordering contract."""
+    import torch
+    sc = make_scene(30000, seed=222, log_scale_mean=float(np.log(0.02)))
+    _upload(rasterizer, sc)
+    cams = [ring_camera(300, 200, 240.0, yaw_deg=y, elev=e) for y, e in ((0.0, 0.0), (75.0, 0.3), (200.0, -0.2))]
+    away = cams[1].viewmat.copy()
+    away[:3, :3] = np.diag([-1.0, 1.0, -1.0]).astype(np.float32) @ away[:3, :3]      # turn the camera around
+    away[:3, 3] = np.diag([-1.0, 1.0, -1.0]).astype(np.float32) @ away[:3, 3]
+    Vs = np.stack([cams[0].viewmat, away, cams[2].viewmat])
+    Ks = np.stack([c.K for c in cams])
+    singles = [{k: v.clone() for k, v in rasterizer.render(Vs[i], Ks[i], 300, 200, BG, want=("rgb", "alpha", "depth", "rgb8"),
+                                                            depth_fill_max=True).items()} for i in range(3)]
+    assert float(singles[1]["alpha"].max()) == 0.0 and float(singles[0]["alpha"].max()) > 0.5
+    batch = rasterizer.render_batch(Vs, Ks, 300, 200, BG, want=("rgb", "alpha", "depth", "rgb8"), depth_fill_max=True)
+    for i in range(3):
+        for k in ("rgb", "alpha", "depth", "rgb8"):
+            assert torch.equal(batch[k][i], singles[i][k]), (i, k)
+    # asynchronous pairs: work on the caller's stream after the call is ordered behind the previous batch
+    outs = [{"rgb": torch.empty((2, 200, 300, 3), device="cuda:0")} for _ in range(3)]
+    snaps = []
+    for j in range(3):
+        rasterizer.render_batch(Vs[[0, 2]], Ks[[0, 2]], 300, 200, BG, want=("rgb",), out=outs[j], block=False)
+        if j > 0:
+            snaps.append(outs[j - 1]["rgb"].clone())
+    rasterizer.wait()
+    for sn in snaps + [o["rgb"] for o in outs]:
+        assert torch.equal(sn[0], singles[0]["rgb"]) and torch.equal(sn[1], singles[2]["rgb"])
+
+
 def test_c_abi_error_paths_and_timing_means():
     """Status codes instead of exceptions across the ABI; the wrapper raises RuntimeError (SasError)."""
     import ctypes
