@@ -94,6 +94,7 @@ struct sas_ctx {
     SasScene scene{};
     bool has_scene = false;
     std::vector<float> group_host;
+    float *groups_pinned = nullptr;   // [256 * 12] pinned staging of the group poses, re-read by every frame
     // frames
     Slot slots[kMaxSlots];
     int n_slots = 4;     // frames that may be enqueued (SAS_SLOTS=1..4); run_depth of them execute at once
@@ -286,6 +287,9 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
         HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
         if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
         HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, counter_bytes(tiles), st));
+        if (c->scene.group_Rt)   // frames in flight at the same time carry the same poses: set_group_poses drains first
+            HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups,
+                                      hipMemcpyHostToDevice, st));
     }
     if (role == ROLE_LEADER) {
         const int ptiles = partner->cam.tw * partner->cam.th;
@@ -519,6 +523,7 @@ int sas_create(int device, sas_ctx **out)
         ok = ok && hipStreamCreateWithPriority(&c->s_front, hipStreamNonBlocking, prio == 2 ? hi : (prio == 1 ? lo : 0)) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->s_tile, hipStreamNonBlocking, prio == 1 ? hi : (prio == 2 ? lo : 0)) == hipSuccess;
     }
+    ok = ok && hipHostMalloc((void **)&c->groups_pinned, sizeof(float) * 12 * 256) == hipSuccess;
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&sl.params_host, sizeof(SasParams)) == hipSuccess;
@@ -547,6 +552,7 @@ int sas_destroy(sas_ctx *c)
     (void)hipSetDevice(c->device);
     for (hipStream_t *ps : {&c->s_front, &c->s_tile})
         if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+    if (c->groups_pinned) { (void)hipHostFree(c->groups_pinned); c->groups_pinned = nullptr; }
     for (Slot &sl : c->slots) {
         if (sl.fs) (void)hipStreamSynchronize(sl.fs);
         for (auto &sd : sl.sort_streams.side)
@@ -667,7 +673,8 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
         c->group_host.assign((size_t)12 * n_groups, 0.0f);
         for (int g = 0; g < n_groups; ++g) c->group_host[12 * g + 0] = c->group_host[12 * g + 5] = c->group_host[12 * g + 10] = 1.0f;
         if ((rc = ensure(c, c->groups, sizeof(float) * 12 * 256))) return rc;
-        HIP_TRY(c, hipMemcpy(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice));
+        memcpy(c->groups_pinned, c->group_host.data(), sizeof(float) * 12 * n_groups);
+        HIP_TRY(c, hipMemcpy(c->groups.p, c->groups_pinned, sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice));
         c->scene.group_Rt = (const float *)c->groups.p;
     }
     for (Slot &sl : c->slots) sl.scr.cap = 0;  // re-derive the intersection capacity for the new scene
@@ -688,9 +695,11 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
         if (rc) return rc;
     }
     c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
-    // no frame is in flight here; later frames start behind the caller's stream, where this copy is queued
-    HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->group_host.data(), sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice,
-                              c->stream));
+    // No frame is in flight here.  The poses go into a pinned staging block that every frame copies
+    // to the device on its own stream (a node of its captured graph, re-read at each replay) -- like
+    // the per-frame parameter block.  A host-to-device copy from pageable memory issued here, between
+    // two replays of a frame graph, ended in GPU write faults on ROCm 7.2.
+    memcpy(c->groups_pinned, Rt, sizeof(float) * 12 * n_groups);
     return SAS_OK;
 }
 

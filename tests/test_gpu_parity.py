@@ -361,6 +361,24 @@ def test_view_pairs_equal_single_views(rasterizer):
         assert torch.equal(sn[0], singles[0]["rgb"]) and torch.equal(sn[1], singles[2]["rgb"])
 
 
+def test_group_pose_updates_between_graph_replays(rasterizer):
+    """Regression: per-step set_group_poses between replays of the captured frame graphs (the Gym loop:
+    poses, then one blocking render per camera) -- once a GPU write fault when the poses were copied
+    from pageable memory between two replays.  Frames follow the poses of their step."""
+    sc = make_scene(20000, seed=333, log_scale_mean=float(np.log(0.03)), n_groups=5)
+    _upload(rasterizer, sc, group_id=sc.group_id, n_groups=5)
+    cams = [ring_camera(160, 120, 130.0, yaw_deg=0.0), ring_camera(160, 120, 130.0, yaw_deg=70.0, elev=0.4)]
+    last = None
+    for step in range(12):                       # every frame slot captures once and replays several times
+        Rt = random_group_poses(5, seed=step)
+        rasterizer.set_group_poses(Rt)
+        last = [rasterizer.render(c.viewmat, c.K, 160, 120, BG, want=("rgb8", "rgb"))["rgb"].cpu().numpy() for c in cams]
+    for c, got in zip(cams, last):
+        ref = oracle.render(sc.means, sc.opacities, sc.sh, c.viewmat, c.K, 160, 120, quats=sc.quats, scales=sc.scales,
+                            sh_degree=3, group_id=sc.group_id, group_Rt=random_group_poses(5, seed=11), background=BG)
+        assert np.array_equal(got, ref["rgb"])
+
+
 def test_c_abi_error_paths_and_timing_means():
     """Status codes instead of exceptions across the ABI; the wrapper raises RuntimeError (SasError)."""
     import ctypes
