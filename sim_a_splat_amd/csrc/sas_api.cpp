@@ -103,7 +103,11 @@ struct sas_ctx {
     int last_slot = 0;   // most recently enqueued (parity hooks)
     hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
     bool has_frame = false;
-    bool use_graphs = true;         // SAS_NO_GRAPH=1 disables frame graphs
+    // Captured frame graphs are opt-in (SAS_GRAPH=1).  On ROCm 7.2 a replay that follows ANY host-to-device
+    // copy from pageable memory issued after the capture (the caller's own torch.tensor(x).cuda(), say)
+    // ends in a GPU write fault ("write access to a read-only page"); eager launches cost the host
+    // ~25 runtime calls per frame, which two frames in flight hide completely (same frames/s).
+    bool use_graphs = false;
     // Stage pipelining (SAS_PIPELINE=1): binning (project, scan, scatter) of every frame on s_front,
     // tile kernel + tail on s_tile.  Binning is HBM/latency-bound, the tile kernel VALU-bound: with
     // both streams in order, the tile kernels run back to back while the next frame is binned.
@@ -113,7 +117,10 @@ struct sas_ctx {
     // are queued on the GPU behind done events, so no host round trip sits between a frame
     // finishing and the next one starting.
     int run_depth = 2;   // SAS_RUN_DEPTH; 0: same as n_slots
-    bool pair_views = true;   // sas_render_batch projects two views per pass over the scene (SAS_PAIR=0 disables)
+    // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
+    // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
+    int pair_views = -1;            // -1: by scene size
+    static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
@@ -361,8 +368,8 @@ int prepare_frame(sas_ctx *c, Slot &sl)
 }
 
 // Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
-// Untimed single frames replay a hipGraph captured once per (slot, image size, flags, scene,
-// scratch): one launch instead of ~25 runtime calls.  The two frames of a view pair (role, partner;
+// With SAS_GRAPH=1, untimed single frames replay a hipGraph captured once per (slot, image size,
+// flags, scene, scratch): one launch instead of ~25 runtime calls (see sas_ctx::use_graphs).  The two frames of a view pair (role, partner;
 // both prepared by the caller) are enqueued eagerly.
 int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = nullptr)
 {
@@ -507,6 +514,7 @@ int sas_create(int device, sas_ctx **out)
     if (!c) return SAS_ERR_OOM;
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess;
+    if (const char *e = getenv("SAS_GRAPH")) c->use_graphs = atoi(e) != 0;
     if (const char *e = getenv("SAS_NO_GRAPH"))
         if (atoi(e) != 0) c->use_graphs = false;
     if (const char *e = getenv("SAS_SLOTS")) {
@@ -515,7 +523,7 @@ int sas_create(int device, sas_ctx **out)
     }
     if (const char *e = getenv("SAS_PIPELINE")) c->pipeline = atoi(e);
     if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
-    if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0;
+    if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0 ? 1 : 0;
     if (c->pipeline) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -823,7 +831,8 @@ int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float
     };
     // Views go through the frame slots two at a time: one pass over the scene projects both
     // (timed and full-sort frames keep to one view per pass).
-    const bool pair = c->pair_views && c->n_slots >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
+    const bool want_pairs = c->pair_views < 0 ? c->scene.n >= sas_ctx::kPairMinGaussians : c->pair_views != 0;
+    const bool pair = want_pairs && c->n_slots >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
     for (int v = 0; v < n_views;) {
         const int n = (pair && v + 1 < n_views) ? 2 : 1;
         const ViewCall vc[2] = {view(v), view(n == 2 ? v + 1 : v)};

@@ -262,6 +262,15 @@ def test_full_size_config_against_oracle(rasterizer, cfg):
     assert a.min() >= 0.0 and a.max() <= 1.0
     empty = a[..., 0] == 0
     assert empty.any() and np.array_equal(got["rgb"][empty], np.broadcast_to(np.array(BG, np.float32), got["rgb"][empty].shape))
+    if cfg == 3:
+        # the bench's step at full size: a view pair through sas_render_batch (paired by default at this
+        # scene size); its first view is the frame just checked against the oracle
+        import torch
+        cam2 = ring_camera(cams[0].width, cams[0].height, float(cams[0].K[0, 0]), yaw_deg=180.0)
+        pair = rasterizer.render_batch(np.stack([cams[0].viewmat, cam2.viewmat]), np.stack([cams[0].K, cam2.K]),
+                                       cams[0].width, cams[0].height, BG, want=("rgb",))["rgb"]
+        alone = rasterizer.render(cam2.viewmat, cam2.K, cam2.width, cam2.height, BG, want=("rgb",))["rgb"]
+        assert np.array_equal(pair[0].cpu().numpy(), got["rgb"]) and torch.equal(pair[1], alone)
 
 
 def test_background_enters_linearly_at_full_size(rasterizer):
@@ -329,11 +338,15 @@ def test_config4_eight_poses_uint8_batched(rasterizer):
         assert np.array_equal(got8[v], ref["rgb8"]) and np.array_equal(got[v], ref["rgb"])
 
 
-def test_view_pairs_equal_single_views(rasterizer):
-    """sas_render_batch projects two views per pass over the scene: every output of every view of an
-    odd-sized batch (pairs + one single), one of them looking away from the scene, equals the
-    one-view-at-a-time render; an asynchronous batch keeps the stream-ordering contract."""
+def test_view_pairs_equal_single_views(monkeypatch):
+    """sas_render_batch projects two views per pass over the scene (by default for scenes of 0.5 M
+    Gaussians and more; forced here): every output of every view of an odd-sized batch (pairs + one
+    single), one of them looking away from the scene, equals the one-view-at-a-time render; an
+    asynchronous batch keeps the stream-ordering contract."""
     import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_PAIR", "1")
+    rasterizer = Rasterizer("cuda:0")
     sc = make_scene(30000, seed=222, log_scale_mean=float(np.log(0.02)))
     _upload(rasterizer, sc)
     cams = [ring_camera(300, 200, 240.0, yaw_deg=y, elev=e) for y, e in ((0.0, 0.0), (75.0, 0.3), (200.0, -0.2))]
@@ -359,6 +372,7 @@ def test_view_pairs_equal_single_views(rasterizer):
     rasterizer.wait()
     for sn in snaps + [o["rgb"] for o in outs]:
         assert torch.equal(sn[0], singles[0]["rgb"]) and torch.equal(sn[1], singles[2]["rgb"])
+    rasterizer.close()
 
 
 def test_group_pose_updates_between_graph_replays(rasterizer):
