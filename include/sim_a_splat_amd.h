@@ -42,7 +42,7 @@ typedef enum {
 
 /* sas_render flags */
 #define SAS_DEPTH_FILL_MAX 1u /* depth = where(alpha > 0, ED, max(ED)): nerfstudio get_outputs (T0) */
-#define SAS_ASYNC 2u          /* enqueue only (<= 2 frames in flight); results valid after sas_wait(); work put on
+#define SAS_ASYNC 2u          /* enqueue only (<= 4 frames enqueued, 2 executing); results valid after sas_wait(); work put on
                                  `stream` after sas_render(i) returns is ordered behind frame i-1 */
 #define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
 #define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
@@ -116,8 +116,10 @@ int sas_render_rgbd(sas_ctx *ctx, const float viewmat[16], const float K[9], int
  * Render n_views views of the same size in one call.  Serves the per-camera loops of
  * SplatHandler.render / SplatEnvWrapper.render (splat_handler.py:337-345, splat_env_wrapper.py:147-158).
  *   viewmats [n_views,16], Ks [n_views,9] host arrays; outputs are [n_views,H,W,...] device arrays
- *   (any may be NULL).  The views go through the two frame slots back to back (consecutive views
- * overlap on the GPU); the call returns when all are complete unless SAS_ASYNC is given.
+ *   (any may be NULL).  The views go through the frame slots back to back (consecutive views overlap on
+ * the GPU; for scenes of >= 0.5 M Gaussians two views share one projection pass over the scene); the call
+ * returns when all are complete unless SAS_ASYNC is given, and then work put on `stream` afterwards is
+ * ordered behind every view but the last one submitted.
  */
 int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                      const float *background, unsigned flags, float *rgb, float *alpha, float *depth,

@@ -4,6 +4,7 @@ coalesced reads (MI355X_MICROARCH.md, HBM section; confirmed on k_project: 240 M
 import collections
 import csv
 import json
+import re
 import sys
 from pathlib import Path
 
@@ -15,7 +16,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"]
-            short = name.split("::")[-1].split("(")[0].split("<")[0]
+            short = re.split(r"[(<]", re.sub(r"\(anonymous namespace\)::|^void ", "", name))[0]
             acc[short].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
