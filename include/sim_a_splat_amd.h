@@ -93,7 +93,9 @@ int sas_set_group_poses(sas_ctx *ctx, int n_groups, const float *Rt);
  *   alpha [H,W]   f32 or NULL     accumulation
  *   depth [H,W]   f32 or NULL     expected depth (see SAS_DEPTH_FILL_MAX)
  *   rgb8  [H,W,3] u8  or NULL     floor(rgb*255 + 0.5)
- *   stream      hipStream_t (NULL = default stream)
+ *   stream      hipStream_t (NULL = default stream): the frame's writes to the output buffers are ordered
+ *               behind everything enqueued on it before the call (the scene itself is synchronised by
+ *               sas_scene_upload / sas_set_group_poses, which return only when their data is in place)
  * Without SAS_ASYNC the call returns after the frame is complete.
  */
 int sas_render(sas_ctx *ctx, const float *viewmat, const float *K, int width, int height,

@@ -49,15 +49,17 @@ struct Scratch {
 // One in-flight frame.  Each slot has its own internal stream (plus two side streams for the
 // concurrent sort classes) and its own scratch: the stages of a frame are each too short on
 // parallelism to fill 256 CUs (a few thousand tiles), so consecutive frames overlap on the chip.
-// The internal stream starts after everything the caller had enqueued on `stream` at the time of
-// sas_render; the caller's stream is made to wait for frame i when frame i+1 is submitted (or in
-// sas_wait), which keeps two frames in flight.
+// A frame writes its output buffers only after everything the caller had enqueued on `stream` at the
+// time of sas_render (its projection and binning, which touch only the scene and the slot's scratch,
+// do not wait for the caller); the caller's stream is made to wait for frame i when frame i+1 is
+// submitted (or in sas_wait), which keeps frames in flight.
 struct Slot {
     RenderArgs args;
     hipStream_t fs = nullptr;
     SasSortStreams sort_streams{};
     hipEvent_t start = nullptr, done = nullptr, front_done = nullptr;
     hipEvent_t pair_ev = nullptr;   // leader of a view pair: both projections are done
+    hipEvent_t gpu_done = nullptr;  // the frame's last kernel is done (gate of later frames; `done` also covers the stats read-back)
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
     unsigned *stats_host = nullptr;  // pinned, 8 words
     Scratch scr;
@@ -280,9 +282,31 @@ size_t counter_bytes(int tiles)
     return (cbytes + 15) & ~(size_t)15;
 }
 
-// The frame's work on stream `st`: parameter block, counters, the five stages, stats read-back.
+// Uploads and clears that depend on nothing on the GPU: the slot's parameter block and counters (for
+// a pair leader also the follower's) and the group poses.  Issued BEFORE the stream waits for the
+// caller's stream and for the frame two back, so that these five small blit kernels (~6 us each, one
+// after the other) run while the previous frames are still compositing instead of in front of the
+// projection.
+int enqueue_prologue(sas_ctx *c, Slot &sl, hipStream_t st, int role, Slot *partner)
+{
+    if (role == ROLE_FOLLOWER) return SAS_OK;
+    const int tiles = sl.cam.tw * sl.cam.th;
+    HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(sl.scr.counters.p, 0, counter_bytes(tiles), st));
+    if (role == ROLE_LEADER) {
+        const int ptiles = partner->cam.tw * partner->cam.th;
+        HIP_TRY(c, hipMemcpyAsync(partner->params_dev.p, partner->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(partner->scr.counters.p, 0, counter_bytes(ptiles), st));
+    }
+    if (c->scene.group_Rt)   // frames in flight at the same time carry the same poses: set_group_poses drains first
+        HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups,
+                                  hipMemcpyHostToDevice, st));
+    return SAS_OK;
+}
+
+// The frame's work on stream `st`: (prologue,) the five stages, stats read-back.
 int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t st_tile = nullptr, int role = ROLE_SINGLE,
-                 Slot *partner = nullptr)
+                 Slot *partner = nullptr, bool with_prologue = true, bool in_capture = false, bool late_start_wait = false)
 {
     const RenderArgs &a = sl.args;
     const SasCam &cam = sl.cam;
@@ -290,18 +314,13 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
     Scratch &q = sl.scr;
     SasFrame f = frame_of(c, q, tiles);
     const SasParams *P = (const SasParams *)sl.params_dev.p;
-    if (role != ROLE_FOLLOWER) {
-        HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-        if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
-        HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, counter_bytes(tiles), st));
-        if (c->scene.group_Rt)   // frames in flight at the same time carry the same poses: set_group_poses drains first
-            HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups,
-                                      hipMemcpyHostToDevice, st));
+    if (with_prologue) {
+        const int rc = enqueue_prologue(c, sl, st, role, partner);
+        if (rc) return rc;
     }
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
     if (role == ROLE_LEADER) {
         const int ptiles = partner->cam.tw * partner->cam.th;
-        HIP_TRY(c, hipMemcpyAsync(partner->params_dev.p, partner->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(partner->scr.counters.p, 0, counter_bytes(ptiles), st));
         sas_launch_project2(st, c->scene, P, f, (const SasParams *)partner->params_dev.p, frame_of(c, partner->scr, ptiles));
         HIP_TRY(c, hipEventRecord(sl.pair_ev, st));
     } else if (role == ROLE_SINGLE) {
@@ -318,6 +337,12 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
         HIP_TRY(c, hipStreamWaitEvent(st_tile, sl.front_done, 0));
         st = st_tile;
     }
+    // The caller's stream matters to a frame only through the output buffers (a consumer of an earlier
+    // frame may still be reading the buffer this frame will overwrite): everything up to here touches
+    // only the scene and the slot's scratch, so the wait for the caller's work sits here, where it has
+    // long been satisfied, and not in front of the projection (where it chained every frame behind the
+    // stats read-back of the frame two back through two extra cross-queue event hops).
+    if (late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
@@ -329,6 +354,7 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
     const bool pts = a.depth && (a.points || a.mask);
     if (fill || pts) sas_launch_depth_tail(st, tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
+    if (!in_capture) HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return SAS_OK;
 }
@@ -383,18 +409,24 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     const bool piped = c->pipeline && !timing && !(a.flags & SAS_FULL_SORT) && role == ROLE_SINGLE;
     hipStream_t st = piped ? c->s_front : sl.fs;
     hipStream_t st_end = piped ? c->s_tile : sl.fs;
-    // start after whatever the caller has enqueued on its stream so far
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
+    const bool graphed = !timing && !ttiles && !piped && role == ROLE_SINGLE && c->use_graphs;
+    // eager frames: the uploads go first, ahead of every wait (the slot's own previous frame is complete)
+    const bool early_prologue = !graphed && !timing;
+    if (early_prologue && (rc = enqueue_prologue(c, sl, st, role, partner))) return rc;
+    // after whatever the caller has enqueued on its stream so far: graph and timed frames as a whole,
+    // eager frames from the tile kernel on (enqueue_body)
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
-    HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    const bool late_start_wait = early_prologue && !piped;
+    if (!late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
     if (c->run_depth > 0 && c->run_depth < c->n_slots) {
         const int me = (int)(&sl - c->slots);
         Slot &gate = c->slots[(me + c->n_slots - c->run_depth) % c->n_slots];   // frame j - run_depth
-        HIP_TRY(c, hipStreamWaitEvent(st, gate.done, 0));
+        HIP_TRY(c, hipStreamWaitEvent(st, gate.gpu_done, 0));
     }
     bool launched = false;
-    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
-    if (!timing && !ttiles && !piped && role == ROLE_SINGLE && c->use_graphs) {
+    if (graphed) {
         Slot::GraphKey key;
         key.W = a.W; key.H = a.H;
         key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
@@ -407,7 +439,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
             hipGraph_t graph = nullptr;
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok) {
-                const int brc = enqueue_body(c, sl, st, false);
+                const int brc = enqueue_body(c, sl, st, false, nullptr, ROLE_SINGLE, nullptr, true, true);
                 const hipError_t ee = hipStreamEndCapture(st, &graph);
                 ok = brc == SAS_OK && ee == hipSuccess && graph != nullptr;
             }
@@ -423,11 +455,12 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
         }
         if (sl.gexec) {
             HIP_TRY(c, hipGraphLaunch(sl.gexec, st));
+            HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
             launched = true;
         }
     }
     if (!launched) {
-        rc = enqueue_body(c, sl, st, timing, st_end, role, partner);
+        rc = enqueue_body(c, sl, st, timing, st_end, role, partner, !early_prologue, false, late_start_wait);
         if (rc) return rc;
         HIP_TRY(c, hipGetLastError());
     }
@@ -540,6 +573,7 @@ int sas_create(int device, sas_ctx **out)
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.pair_ev, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sl.gpu_done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         for (auto &sd : sl.sort_streams.side) ok = ok && hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.sort_streams.fork, hipEventDisableTiming) == hipSuccess;
@@ -577,6 +611,7 @@ int sas_destroy(sas_ctx *c)
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.front_done) (void)hipEventDestroy(sl.front_done);
         if (sl.pair_ev) (void)hipEventDestroy(sl.pair_ev);
+        if (sl.gpu_done) (void)hipEventDestroy(sl.gpu_done);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
