@@ -85,7 +85,7 @@ struct Slot {
     } gkey;
 };
 
-constexpr int kMaxSlots = 4;
+constexpr int kMaxSlots = 8;
 
 struct sas_ctx {
     int device = 0;
@@ -99,7 +99,7 @@ struct sas_ctx {
     float *groups_pinned = nullptr;   // [256 * 12] pinned staging of the group poses, re-read by every frame
     // frames
     Slot slots[kMaxSlots];
-    int n_slots = 4;     // frames that may be enqueued (SAS_SLOTS=1..4); run_depth of them execute at once
+    int n_slots = 4;     // frames that may be enqueued (SAS_SLOTS=1..8; 6 and 8 are slower)
     int head = 0;        // oldest busy slot
     int inflight = 0;
     int last_slot = 0;   // most recently enqueued (parity hooks)
@@ -115,10 +115,9 @@ struct sas_ctx {
     // both streams in order, the tile kernels run back to back while the next frame is binned.
     int pipeline = 0;
     hipStream_t s_front = nullptr, s_tile = nullptr;
-    // Frames that may EXECUTE at once (<= n_slots).  With more slots than that, the extra frames
-    // are queued on the GPU behind done events, so no host round trip sits between a frame
-    // finishing and the next one starting.
-    int run_depth = 2;   // SAS_RUN_DEPTH; 0: same as n_slots
+    // Optional cap on the frames that may EXECUTE at once (< n_slots): the extra frames are then queued
+    // on the GPU behind the last kernel of the frame run_depth back.
+    int run_depth = 0;   // SAS_RUN_DEPTH; 0: every enqueued frame may execute (best measured: 4 slots, ungated)
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
