@@ -57,7 +57,7 @@ struct Slot {
     RenderArgs args;
     hipStream_t fs = nullptr;
     SasSortStreams sort_streams{};
-    hipEvent_t start = nullptr, done = nullptr, front_done = nullptr;
+    hipEvent_t start = nullptr, done = nullptr;
     hipEvent_t pair_ev = nullptr;   // leader of a view pair: both projections are done
     hipEvent_t gpu_done = nullptr;  // the frame's last kernel is done (gate of later frames; `done` also covers the stats read-back)
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
@@ -110,11 +110,6 @@ struct sas_ctx {
     // ends in a GPU write fault ("write access to a read-only page"); eager launches cost the host
     // ~25 runtime calls per frame, which two frames in flight hide completely (same frames/s).
     bool use_graphs = false;
-    // Stage pipelining (SAS_PIPELINE=1): binning (project, scan, scatter) of every frame on s_front,
-    // tile kernel + tail on s_tile.  Binning is HBM/latency-bound, the tile kernel VALU-bound: with
-    // both streams in order, the tile kernels run back to back while the next frame is binned.
-    int pipeline = 0;
-    hipStream_t s_front = nullptr, s_tile = nullptr;
     // Optional cap on the frames that may EXECUTE at once (< n_slots): the extra frames are then queued
     // on the GPU behind the last kernel of the frame run_depth back.
     int run_depth = 0;   // SAS_RUN_DEPTH; 0: every enqueued frame may execute (best measured: 4 slots, ungated)
@@ -304,7 +299,7 @@ int enqueue_prologue(sas_ctx *c, Slot &sl, hipStream_t st, int role, Slot *partn
 }
 
 // The frame's work on stream `st`: (prologue,) the five stages, stats read-back.
-int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t st_tile = nullptr, int role = ROLE_SINGLE,
+int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role = ROLE_SINGLE,
                  Slot *partner = nullptr, bool with_prologue = true, bool in_capture = false, bool late_start_wait = false)
 {
     const RenderArgs &a = sl.args;
@@ -331,11 +326,6 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, hipStream_t 
     sas_launch_scatter(st, c->scene, cam.tw, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
     const bool full = (a.flags & SAS_FULL_SORT) != 0;
-    if (st_tile && st_tile != st) {   // pipelined: the rest of the frame runs on the tile stream
-        HIP_TRY(c, hipEventRecord(sl.front_done, st));
-        HIP_TRY(c, hipStreamWaitEvent(st_tile, sl.front_done, 0));
-        st = st_tile;
-    }
     // The caller's stream matters to a frame only through the output buffers (a consumer of an earlier
     // frame may still be reading the buffer this frame will overwrite): everything up to here touches
     // only the scene and the slot's scratch, so the wait for the caller's work sits here, where it has
@@ -405,18 +395,16 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     Scratch &q = sl.scr;
 
     const bool timing = (a.flags & SAS_TIMING) != 0;
-    const bool piped = c->pipeline && !timing && !(a.flags & SAS_FULL_SORT) && role == ROLE_SINGLE;
-    hipStream_t st = piped ? c->s_front : sl.fs;
-    hipStream_t st_end = piped ? c->s_tile : sl.fs;
+    hipStream_t st = sl.fs;
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
-    const bool graphed = !timing && !ttiles && !piped && role == ROLE_SINGLE && c->use_graphs;
+    const bool graphed = !timing && !ttiles && role == ROLE_SINGLE && c->use_graphs;
     // eager frames: the uploads go first, ahead of every wait (the slot's own previous frame is complete)
     const bool early_prologue = !graphed && !timing;
     if (early_prologue && (rc = enqueue_prologue(c, sl, st, role, partner))) return rc;
     // after whatever the caller has enqueued on its stream so far: graph and timed frames as a whole,
     // eager frames from the tile kernel on (enqueue_body)
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
-    const bool late_start_wait = early_prologue && !piped;
+    const bool late_start_wait = early_prologue;
     if (!late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
     if (c->run_depth > 0 && c->run_depth < c->n_slots) {
@@ -438,7 +426,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
             hipGraph_t graph = nullptr;
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok) {
-                const int brc = enqueue_body(c, sl, st, false, nullptr, ROLE_SINGLE, nullptr, true, true);
+                const int brc = enqueue_body(c, sl, st, false, ROLE_SINGLE, nullptr, true, true);
                 const hipError_t ee = hipStreamEndCapture(st, &graph);
                 ok = brc == SAS_OK && ee == hipSuccess && graph != nullptr;
             }
@@ -459,13 +447,13 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
         }
     }
     if (!launched) {
-        rc = enqueue_body(c, sl, st, timing, st_end, role, partner, !early_prologue, false, late_start_wait);
+        rc = enqueue_body(c, sl, st, timing, role, partner, !early_prologue, false, late_start_wait);
         if (rc) return rc;
         HIP_TRY(c, hipGetLastError());
     }
     sl.timed = timing;
     sl.timed_tiles = ttiles && !timing && !(a.flags & SAS_FULL_SORT);
-    HIP_TRY(c, hipEventRecord(sl.done, st_end));
+    HIP_TRY(c, hipEventRecord(sl.done, st));
     sl.busy = true;
     c->has_frame = true;
     return SAS_OK;
@@ -553,16 +541,8 @@ int sas_create(int device, sas_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= kMaxSlots) c->n_slots = v;
     }
-    if (const char *e = getenv("SAS_PIPELINE")) c->pipeline = atoi(e);
     if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
     if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0 ? 1 : 0;
-    if (c->pipeline) {
-        int lo = 0, hi = 0;   // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const int prio = getenv("SAS_PRIO") ? atoi(getenv("SAS_PRIO")) : 0;   // 1: tile stream first, 2: binning first
-        ok = ok && hipStreamCreateWithPriority(&c->s_front, hipStreamNonBlocking, prio == 2 ? hi : (prio == 1 ? lo : 0)) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->s_tile, hipStreamNonBlocking, prio == 1 ? hi : (prio == 2 ? lo : 0)) == hipSuccess;
-    }
     ok = ok && hipHostMalloc((void **)&c->groups_pinned, sizeof(float) * 12 * 256) == hipSuccess;
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
@@ -570,7 +550,6 @@ int sas_create(int device, sas_ctx **out)
         ok = ok && hipStreamCreateWithFlags(&sl.fs, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.pair_ev, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.gpu_done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -591,8 +570,6 @@ int sas_destroy(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    for (hipStream_t *ps : {&c->s_front, &c->s_tile})
-        if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
     if (c->groups_pinned) { (void)hipHostFree(c->groups_pinned); c->groups_pinned = nullptr; }
     for (Slot &sl : c->slots) {
         if (sl.fs) (void)hipStreamSynchronize(sl.fs);
@@ -608,7 +585,6 @@ int sas_destroy(sas_ctx *c)
         release(sl.params_dev);
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
-        if (sl.front_done) (void)hipEventDestroy(sl.front_done);
         if (sl.pair_ev) (void)hipEventDestroy(sl.pair_ev);
         if (sl.gpu_done) (void)hipEventDestroy(sl.gpu_done);
         for (auto &e : sl.ev)
