@@ -5,11 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path (project + SH, bin, per-tile sort, blend) over one synthetic
-1M-Gaussian scene resident in HBM, one 1080p view per GPU, float32 RGB out.  With N > 1 every
-rank renders its own view of the replicated scene (weak scaling) and the finished
-frames are gathered to rank 0 over RCCL, one frame behind the renderer.  Rank 0 prints ONE JSON
-line.  The oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
+A step is one pass of the hot path (project + SH, bin, per-tile sort, blend) over one batch of two
+independent 1080p views per GPU (one sas_render_batch call; the pair shares one projection pass) of
+one synthetic 1M-Gaussian scene resident in HBM, float32 RGB + uint8 RGB out per view.  With N > 1
+every rank renders its own views of the replicated scene (weak scaling) and the finished
+uint8 frames are gathered to rank 0 over RCCL, one step behind the renderer.  Rank 0 prints ONE JSON
+line; value = frames/s over all ranks.  The oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
 """
 from __future__ import annotations
 
@@ -181,7 +182,7 @@ def main():
                                    + ", float32 RGB + uint8 RGB out per view",
                        "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
                        "views_per_step": world * VPS, "parallelism": f"views{world}x{VPS}",
-                       "gather": "uint8 frames to rank 0 (RCCL), one frame behind the renderer" if world > 1 else "none"},
+                       "gather": "uint8 frames to rank 0 (RCCL), one step behind the renderer" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy"),
                          "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames,
