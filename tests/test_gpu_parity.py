@@ -393,6 +393,35 @@ def test_group_pose_updates_between_graph_replays(rasterizer):
         assert np.array_equal(got, ref["rgb"])
 
 
+def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch):
+    """More intersections than the initial buffer holds (max(4 N, 2^20) keys): the frame is detected as
+    overflowed from its stats, the buffer grows to the measured need and the frame is rendered again --
+    for a blocking single view, and for both views of an asynchronous pair."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_PAIR", "1")
+    r = Rasterizer("cuda:0")
+    sc = make_scene(30000, seed=444, log_scale_mean=float(np.log(0.12)))
+    _upload(r, sc)
+    cams = [ring_camera(640, 480, 500.0, yaw_deg=0.0), ring_camera(640, 480, 500.0, yaw_deg=90.0)]
+    refs = [oracle.render_scene(sc, c, background=BG) for c in cams]
+    assert min(ref["n_isect"] for ref in refs) > (1 << 20)
+    got = r.render(cams[0].viewmat, cams[0].K, 640, 480, BG, want=("rgb",))["rgb"].cpu().numpy()
+    st = r.stats()
+    assert st["regrows"] >= 1 and st["capacity"] >= st["n_isect"] == refs[0]["n_isect"]
+    assert np.array_equal(got, refs[0]["rgb"])
+    r.close()
+    r = Rasterizer("cuda:0")                     # fresh buffers: now the pair overflows, both slots
+    _upload(r, sc)
+    out = r.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 640, 480, BG, want=("rgb",),
+                         block=False)
+    r.wait()
+    assert r.stats()["regrows"] >= 2
+    for v in range(2):
+        assert np.array_equal(out["rgb"][v].cpu().numpy(), refs[v]["rgb"]), v
+    r.close()
+
+
 def test_c_abi_error_paths_and_timing_means():
     """Status codes instead of exceptions across the ABI; the wrapper raises RuntimeError (SasError)."""
     import ctypes
