@@ -17,6 +17,16 @@ from . import poses
 from .scene import SplatScene
 
 
+def aabb_mask(means, bounds) -> np.ndarray:
+    """Axis-aligned bounding-box mask of ``_load_saved_splats`` (splat_handler.py:91-97): ``bounds`` is
+    [3,2] (min, max per axis) or None for "keep everything" (the reference passes None)."""
+    means = np.asarray(means)
+    if bounds is None:
+        return np.ones(means.shape[0], dtype=bool)
+    b = np.asarray(bounds, dtype=means.dtype)
+    return np.all((means - b[:, 0] >= 0) & (b[:, 1] - means >= 0), axis=-1)
+
+
 class SplatHandler:
     def __init__(self, means, covs, colors, opacities, link_masks: Dict[str, np.ndarray], icp_transformation: np.ndarray,
                  fk_transforms: Sequence[np.ndarray], instance_uid: str = "robot", robot_num: int = 3,
@@ -40,6 +50,24 @@ class SplatHandler:
         rest = ~self.robot_splat_idxs                          # "/scene_ohne_robot" (:112-119)
         self.scene_handle = self.scene.add_gaussian_splats("/scene_ohne_robot", means[rest], covs[rest], colors[rest],
                                                            opacities[rest])
+
+    @classmethod
+    def from_assets(cls, loader, masks_dir, urdf_path, bounds=None, **kw) -> "SplatHandler":
+        """The constructor flow of the reference (splat_handler.py:44-55): Gaussians from a
+        ``GSplatLoader`` (optionally AABB-masked), ``link_masks_global_dict`` (.npy or the pickle-free
+        .npz), ``icp_transformation.npy`` and ``joint_config.npy`` from ``masks_dir``, and the URDF's
+        visual-mesh forward kinematics at that joint configuration."""
+        from pathlib import Path
+        from . import io, urdf_fk
+        d = Path(masks_dir)
+        mfile = d / "link_masks_global_dict.npz"
+        masks = io.load_link_masks(mfile if mfile.exists() else d / "link_masks_global_dict.npy")
+        icp = io.load_icp_transformation(d / "icp_transformation.npy")
+        fk = urdf_fk.visual_mesh_fk(urdf_fk.load(urdf_path), io.load_joint_config(d / "joint_config.npy"))
+        keep = aabb_mask(loader.means.cpu().numpy(), bounds)
+        arr = lambda t: t.cpu().numpy()[keep]
+        masks = {k: np.asarray(v, dtype=bool)[keep] for k, v in masks.items()}
+        return cls(arr(loader.means), arr(loader.covs), arr(loader.colors), arr(loader.opacities), masks, icp, fk, **kw)
 
     def draw_handler(self, msg) -> None:
         """``msg``: lcmt_viewer_draw-shaped (num_links, robot_num[], position[][3], quaternion[][4] wxyz)."""

@@ -185,3 +185,56 @@ def test_door_b_with_the_shipped_masks_and_icp(golden_dir):
     assert ref["n_visible"] > 50_000
     assert np.array_equal(frame, ref["rgb8"])
     h.scene.close()
+
+
+def test_handler_from_assets_files(golden_dir, tmp_path):
+    """SplatHandler.from_assets: the reference's constructor flow from files -- JSON scene through
+    GSplatLoader, pickled link masks, ICP and joint-config .npy, a URDF -- with an AABB crop; one frame
+    against the oracle on the cropped, regrouped arrays."""
+    import json
+    from sim_a_splat_amd import urdf_fk
+    from sim_a_splat_amd.covariance import GSplatLoader
+    from sim_a_splat_amd.handler import SplatHandler, aabb_mask
+    with np.load(golden_dir / "scene_assets_xarm6_1.npz") as z:
+        a = {k: z[k] for k in z.files}
+    n = 6000
+    rng = np.random.default_rng(21)
+    sc = make_scene(n, seed=21, log_scale_mean=float(np.log(0.03)))
+    (tmp_path / "scene.json").write_text(json.dumps({
+        "means": sc.means.tolist(), "rotations": sc.quats.tolist(), "colors": rng.uniform(0, 1, size=(n, 3)).tolist(),
+        "opacities": np.log(sc.opacities / (1 - sc.opacities)).reshape(-1, 1).tolist(), "scalings": np.log(sc.scales).tolist()}))
+    gid = rng.integers(0, 8, size=n)                                     # 7 = no link
+    np.save(tmp_path / "link_masks_global_dict.npy", {f"link{i}": gid == i for i in range(7)}, allow_pickle=True)
+    np.save(tmp_path / "icp_transformation.npy", a["icp_transformation"])
+    np.save(tmp_path / "joint_config.npy", a["joint_config"])
+    chain = "".join(f'<link name="l{i}"><visual><geometry><mesh filename="l{i}.obj"/></geometry></visual></link>' for i in range(7))
+    chain += "".join(f'<joint name="j{i}" type="revolute"><parent link="l{i - 1}"/><child link="l{i}"/>'
+                     f'<origin xyz="0.04 0 0.08" rpy="0 {0.2 * i} 0"/><axis xyz="0 0 1"/></joint>' for i in range(1, 7))
+    (tmp_path / "robot.urdf").write_text(f"<robot>{chain}</robot>")
+    loader = GSplatLoader.from_json(tmp_path / "scene.json")
+    bounds = np.array([[-0.8, 0.8], [-0.8, 0.8], [-0.7, 1.0]], np.float32)
+    h = SplatHandler.from_assets(loader, tmp_path, tmp_path / "robot.urdf", bounds=bounds, device=0)
+    msg = _fake_msg(rng, 7)
+    h.draw_handler(msg)
+    cam_q, cam_p = (0.0, 1.0, 0.0, 0.0), (0.0, 0.0, 3.0)
+    frame = h.render([(np.array(cam_q), np.array(cam_p))], [[120, 160]])[0]
+    # oracle on the same crop and registration order
+    keep = aabb_mask(sc.means, bounds)
+    assert 0.3 * n < keep.sum() < n
+    means, covs = loader.means.numpy()[keep], loader.covs.numpy()[keep]
+    cols, ops, g = loader.colors.numpy()[keep], loader.opacities.numpy()[keep].reshape(-1), gid[keep]
+    order = np.concatenate([np.nonzero(g == i)[0] for i in range(8)])
+    group_of = np.concatenate([np.full((g == i).sum(), i, np.uint8) for i in range(8)])
+    fk = urdf_fk.visual_mesh_fk(urdf_fk.load(tmp_path / "robot.urdf"), a["joint_config"])
+    s, Ri, ti = poses.decompose_icp(a["icp_transformation"])
+    Rt = []
+    for i in range(7):
+        R, t = ref_math.link_splat_pose(Ri, ti, s, fk[i][:3, :3], fk[i][:3, 3], msg.quaternion[i], msg.position[i])
+        Rt.append(poses.rt_to_row12(poses.quat_wxyz_to_matrix(poses.matrix_to_quat_wxyz(R)), t))
+    Rt.append(poses.rt_to_row12(np.eye(3), np.zeros(3)))
+    cov6 = np.stack([covs[:, 0, 0], covs[:, 0, 1], covs[:, 0, 2], covs[:, 1, 1], covs[:, 1, 2], covs[:, 2, 2]], 1)[order]
+    V, K = h.scene._view_and_K(120, 160, cam_q, cam_p, h.scene.camera.fov)
+    ref = oracle.render(means[order], ops[order], cols[order], V, K, 160, 120, cov6=cov6, sh_degree=-1, group_id=group_of,
+                        group_Rt=np.stack(Rt), background=(0, 0, 0), want_rgb8=True)
+    assert ref["n_visible"] > 500 and np.array_equal(frame, ref["rgb8"])
+    h.scene.close()
