@@ -490,6 +490,16 @@ DEV float vgpr_const(unsigned bits)
     return r;
 }
 
+#ifdef SAS_TUNE_WGTIME
+// A/B builds only: begin / end tick (100 MHz) and list length of every workgroup of k_tile_lazy,
+// by launch index (tools/wg_time.py).  Plain stores: same-address atomics would dominate the kernel.
+constexpr int kDbgWgMax = 16384;
+__device__ unsigned long long g_dbg_wg[3 * kDbgWgMax];
+extern "C" int sas_debug_wg(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_wg), sizeof(unsigned long long) * 3 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef SAS_TUNE_STATS
 // A/B builds only: [0] wave-iterations of the compositing loop, [1] of those with a candidate lane,
 // [2] candidate lanes, [3] lanes that composited, [4] staged entries, [5] queued (entry, block) pairs,
@@ -498,6 +508,7 @@ __device__ unsigned long long g_dbg[8];
 extern "C" int sas_debug_counters(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
+
     if (reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return -1;
@@ -805,6 +816,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
 
+#ifdef SAS_TUNE_WGTIME
+    const unsigned long long t_wg0 = wall_clock64();
+#endif
     const int tile = f.tile_order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
@@ -982,6 +996,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
     }
     const float ED = write_pixel(o, p, inside, ix, iy, c.W);
     if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+#ifdef SAS_TUNE_WGTIME
+    if (tid == 0 && blockIdx.x < kDbgWgMax) {
+        g_dbg_wg[3 * blockIdx.x] = t_wg0;
+        g_dbg_wg[3 * blockIdx.x + 1] = wall_clock64();
+        g_dbg_wg[3 * blockIdx.x + 2] = (unsigned long long)n;
+    }
+#endif
 }
 
 // Depth tail, one pass over the depth image after the tile kernel.

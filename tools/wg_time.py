@@ -1,0 +1,37 @@
+"""Per-workgroup timing of the tile kernel (needs a -DSAS_TUNE_WGTIME build): which tiles run longest,
+when they start and end inside the kernel, and how full the chip is over the kernel's duration."""
+import ctypes, sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from sim_a_splat_amd import _capi
+from sim_a_splat_amd.rasterizer import Rasterizer
+from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND as BG, config_scene_and_cameras
+for cfg in [int(a) for a in sys.argv[1:]] or [3]:
+    sc, cams = config_scene_and_cameras(cfg)
+    cam = cams[0]
+    r = Rasterizer(0)
+    r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
+    L = _capi.lib()
+    tiles = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    n = min(tiles, 16384)
+    out = (ctypes.c_uint64 * (3 * n))()
+    for _ in range(3):
+        r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
+    r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",), timing=True)
+    L.sas_debug_wg(out, n)
+    a = np.array(out, dtype=np.uint64).reshape(n, 3).astype(np.int64)
+    t0, t1, ln = a[:, 0], a[:, 1], a[:, 2]
+    k0 = t0.min()
+    s, e = (t0 - k0) * 0.01, (t1 - k0) * 0.01            # us
+    d = e - s
+    print(f"cfg{cfg}: tile kernel {r.stage_times()['blend'] * 1e3:.1f} us by events; workgroups span {e.max():.1f} us; {n} workgroups, "
+          f"sum of durations {d.sum() / 1e3:.1f} ms -> mean residency {d.sum() / e.max():.0f} workgroups")
+    for i in np.argsort(-d)[:5]:
+        print(f"  long: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us")
+    for i in np.argsort(-e)[:3]:
+        print(f"  last: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us")
+    for q in (0.25, 0.5, 0.75, 0.9):
+        print(f"  {int(q * 100)} % of the workgroups have ended by {np.quantile(e, q):6.1f} us", end=";")
+    print()
+    r.close()
