@@ -4,12 +4,12 @@
 // practice happens a fraction of the way into the tile's list, so ordering the whole list (what a
 // global radix sort does) is mostly wasted work.  One workgroup per 16x16 tile (longest list
 // first) buckets the tile's UNSORTED keys by depth (256 buckets over the tile's own depth range),
-// pulls the nearest <= 1024 entries into LDS, radix-sorts only that chunk, composites it, and
+// pulls the nearest <= 512 entries (kChunk) into LDS, radix-sorts only that chunk, composites it, and
 // fetches the next buckets only while some pixel is still alive.
 //
 // Full path (k_sort_* + k_blend, SAS_FULL_SORT): orders every list completely and writes the
 // per-tile lists to memory, exactly the T4/T5 products of the reference (read back by
-// sas_read_tile_lists for the parity tests).  A tile with more than 1024 entries inside one depth
+// sas_read_tile_lists for the parity tests).  A tile with more than kChunk entries inside one depth
 // bucket (e.g. thousands of coplanar splats) is ordered in place by the lazy kernel itself.
 //
 // Both paths composite through the same code (blend_range) and therefore produce identical bits.

@@ -137,7 +137,7 @@ class Rasterizer:
         """Render one view; returns device tensors ``rgb [H,W,3]``, ``alpha [H,W,1]``,
         ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``.
 
-        ``block=False`` only enqueues (SAS_ASYNC): up to two frames are in flight, the result of a
+        ``block=False`` only enqueues (SAS_ASYNC): up to four frames are in flight, the result of a
         frame is valid after ``wait()``; work enqueued on the current stream after ``render`` of frame
         i returns is ordered behind frame i-1.  ``full_sort=True`` orders every tile list
         completely and keeps it for ``read_tile_lists`` (same image, slower)."""
