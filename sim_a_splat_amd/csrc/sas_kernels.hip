@@ -136,8 +136,14 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
 // histogram over that window and leave the CU as ONE global atomic per touched tile instead of
 // one per intersection (device-scope atomics execute at the memory side: ~10 G/s scattered).
 // Gaussians with a large rectangle stay out of the window and use the wave-cooperative walk.
-constexpr int kHistBins = 2048;  // 8 KiB of LDS
-constexpr int kWinRect = 64;     // largest rectangle (tiles) that takes part in the window
+#ifndef SAS_TUNE_HIST
+#define SAS_TUNE_HIST 2048
+#endif
+#ifndef SAS_TUNE_WINRECT
+#define SAS_TUNE_WINRECT 64
+#endif
+constexpr int kHistBins = SAS_TUNE_HIST;      // 8 KiB of LDS
+constexpr int kWinRect = SAS_TUNE_WINRECT;    // largest rectangle (tiles) that takes part in the window
 
 struct Window {
     int X0, Y0, ww, area;   // origin, width, bin count (0: no participant)
