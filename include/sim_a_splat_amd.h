@@ -42,8 +42,12 @@ typedef enum {
 
 /* sas_render flags */
 #define SAS_DEPTH_FILL_MAX 1u /* depth = where(alpha > 0, ED, max(ED)): nerfstudio get_outputs (T0) */
-#define SAS_ASYNC 2u          /* enqueue only (<= 4 frames enqueued, 2 executing); results valid after sas_wait(); work put on
-                                 `stream` after sas_render(i) returns is ordered behind frame i-1 */
+#define SAS_ASYNC 2u          /* enqueue only (<= 4 frames in flight).  Frames COMPLETE in submission order, inside later
+                                 sas_render* calls (when a slot is needed) or sas_wait(): completion = the host has checked
+                                 that the frame fitted its intersection buffer (a frame that did not is rendered again
+                                 first).  A frame's outputs may be consumed -- by the host after a synchronisation, or by
+                                 work put on `stream` afterwards, which is then ordered behind the frame -- only once it
+                                 is complete; sas_frames_completed() tells how many are. */
 #define SAS_FAST_EXP 4u       /* v_exp_f32 instead of the contract polynomial: NOT bit-exact with the oracle */
 #define SAS_TIMING 8u         /* record per-stage hipEvents (readable with sas_stage_times) */
 #define SAS_TIME_TILES 32u    /* HIP events around the tile kernel only (SAS_T_BLEND); frames still pipeline */
@@ -120,16 +124,20 @@ int sas_render_rgbd(sas_ctx *ctx, const float viewmat[16], const float K[9], int
  *   viewmats [n_views,16], Ks [n_views,9] host arrays; outputs are [n_views,H,W,...] device arrays
  *   (any may be NULL).  The views go through the frame slots back to back (consecutive views overlap on
  * the GPU; for scenes of >= 0.5 M Gaussians two views share one projection pass over the scene); the call
- * returns when all are complete unless SAS_ASYNC is given, and then work put on `stream` afterwards is
- * ordered behind every view but the last one submitted.
+ * returns when all are complete unless SAS_ASYNC is given (then see SAS_ASYNC: views complete in order
+ * inside later calls).
  */
 int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                      const float *background, unsigned flags, float *rgb, float *alpha, float *depth,
                      uint8_t *rgb8, void *stream);
 
-/* Complete the last SAS_ASYNC frame: synchronise, and if the intersection buffer overflowed,
- * grow it and render the frame again. */
+/* Complete every SAS_ASYNC frame in flight: synchronise with each, and where its intersection buffer
+ * overflowed grow it and render the frame again. */
 int sas_wait(sas_ctx *ctx);
+
+/* Frames submitted / completed (see SAS_ASYNC) since sas_create; either pointer may be NULL.  Frames
+ * 0 .. *completed-1 (in submission order) are final and `stream` is ordered behind them. */
+int sas_frames_completed(sas_ctx *ctx, int64_t *submitted, int64_t *completed);
 
 const char *sas_last_error(sas_ctx *ctx);
 int sas_stage_times(sas_ctx *ctx, float *ms, int n);

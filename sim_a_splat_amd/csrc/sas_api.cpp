@@ -65,24 +65,9 @@ struct Slot {
     Scratch scr;
     SasCam cam{};
     bool busy = false, timed = false, timed_tiles = false;
-    // per-frame parameter block (pinned host mirror + device copy) and the captured frame graph
+    // per-frame parameter block (pinned host mirror + device copy)
     SasParams *params_host = nullptr;
     DevBuf params_dev;
-    hipGraphExec_t gexec = nullptr;
-    struct GraphKey {
-        int W = 0, H = 0;
-        unsigned flags = 0;
-        int64_t n = -1;
-        long long cap = 0;
-        uint64_t scene_version = 0;
-        const void *keys = nullptr, *rec = nullptr, *tilebuf = nullptr, *counters = nullptr;
-        bool operator==(const GraphKey &o) const
-        {
-            return W == o.W && H == o.H && flags == o.flags && n == o.n && cap == o.cap &&
-                   scene_version == o.scene_version && keys == o.keys && rec == o.rec && tilebuf == o.tilebuf &&
-                   counters == o.counters;
-        }
-    } gkey;
 };
 
 constexpr int kMaxSlots = 8;
@@ -105,11 +90,6 @@ struct sas_ctx {
     int last_slot = 0;   // most recently enqueued (parity hooks)
     hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
     bool has_frame = false;
-    // Captured frame graphs are opt-in (SAS_GRAPH=1).  On ROCm 7.2 a replay that follows ANY host-to-device
-    // copy from pageable memory issued after the capture (the caller's own torch.tensor(x).cuda(), say)
-    // ends in a GPU write fault ("write access to a read-only page"); eager launches cost the host
-    // ~25 runtime calls per frame, which two frames in flight hide completely (same frames/s).
-    bool use_graphs = false;
     // Optional cap on the frames that may EXECUTE at once (< n_slots): the extra frames are then queued
     // on the GPU behind the last kernel of the frame run_depth back.
     int run_depth = 0;   // SAS_RUN_DEPTH; 0: every enqueued frame may execute (best measured: 4 slots, ungated)
@@ -118,6 +98,7 @@ struct sas_ctx {
     int pair_views = -1;            // -1: by scene size
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
+    int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
     int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
@@ -299,8 +280,8 @@ int enqueue_prologue(sas_ctx *c, Slot &sl, hipStream_t st, int role, Slot *partn
 }
 
 // The frame's work on stream `st`: (prologue,) the five stages, stats read-back.
-int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role = ROLE_SINGLE,
-                 Slot *partner = nullptr, bool with_prologue = true, bool in_capture = false, bool late_start_wait = false)
+int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role, Slot *partner, bool with_prologue,
+                 bool late_start_wait)
 {
     const RenderArgs &a = sl.args;
     const SasCam &cam = sl.cam;
@@ -343,7 +324,7 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role = R
     const bool pts = a.depth && (a.points || a.mask);
     if (fill || pts) sas_launch_depth_tail(st, tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
-    if (!in_capture) HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
+    HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return SAS_OK;
 }
@@ -359,7 +340,9 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     Scratch &q = sl.scr;
     int rc;
     if (q.cap == 0) {
-        long long want = 4 * (long long)n;
+        // 8 intersections per Gaussian to start with (trained scenes and the BASELINE configs need 4-5);
+        // 12 bytes each: 96 MB per slot at 1 M Gaussians.  A frame that needs more is rendered again.
+        long long want = 8 * (long long)n;
         if (want < (1ll << 20)) want = 1ll << 20;
         q.cap = want;
     }
@@ -382,27 +365,23 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     return SAS_OK;
 }
 
-// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).
-// With SAS_GRAPH=1, untimed single frames replay a hipGraph captured once per (slot, image size,
-// flags, scene, scratch): one launch instead of ~25 runtime calls (see sas_ctx::use_graphs).  The two frames of a view pair (role, partner;
-// both prepared by the caller) are enqueued eagerly.
+// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).  Every frame is
+// launched eagerly (~25 runtime calls, hidden by the frames in flight).  The two frames of a view pair
+// (role, partner; both prepared by the caller) share the leader's projection.
 int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = nullptr)
 {
     const RenderArgs &a = sl.args;
     int rc;
     if (role == ROLE_SINGLE && (rc = prepare_frame(c, sl))) return rc;
-    const int64_t n = c->scene.n;
-    Scratch &q = sl.scr;
 
     const bool timing = (a.flags & SAS_TIMING) != 0;
     hipStream_t st = sl.fs;
-    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;   // timed frames take the eager path
-    const bool graphed = !timing && !ttiles && role == ROLE_SINGLE && c->use_graphs;
-    // eager frames: the uploads go first, ahead of every wait (the slot's own previous frame is complete)
-    const bool early_prologue = !graphed && !timing;
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
+    // untimed frames: the uploads go first, ahead of every wait (the slot's own previous frame is complete)
+    const bool early_prologue = !timing;
     if (early_prologue && (rc = enqueue_prologue(c, sl, st, role, partner))) return rc;
-    // after whatever the caller has enqueued on its stream so far: graph and timed frames as a whole,
-    // eager frames from the tile kernel on (enqueue_body)
+    // after whatever the caller has enqueued on its stream so far: timed frames as a whole, the others
+    // from the tile kernel on (enqueue_body)
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     const bool late_start_wait = early_prologue;
     if (!late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
@@ -412,45 +391,9 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
         Slot &gate = c->slots[(me + c->n_slots - c->run_depth) % c->n_slots];   // frame j - run_depth
         HIP_TRY(c, hipStreamWaitEvent(st, gate.gpu_done, 0));
     }
-    bool launched = false;
-    if (graphed) {
-        Slot::GraphKey key;
-        key.W = a.W; key.H = a.H;
-        key.flags = a.flags & (SAS_FAST_EXP | SAS_DEPTH_FILL_MAX | SAS_FULL_SORT);
-        if (!a.depth) key.flags &= ~SAS_DEPTH_FILL_MAX;
-        if (a.depth && (a.points || a.mask)) key.flags |= 1u << 31;   // the tail also unprojects
-        key.n = n; key.cap = q.cap; key.scene_version = c->scene_version;
-        key.keys = q.keys.p; key.rec = q.rec.p; key.tilebuf = q.tilebuf.p; key.counters = q.counters.p;
-        if (!sl.gexec || !(key == sl.gkey)) {
-            if (sl.gexec) { (void)hipGraphExecDestroy(sl.gexec); sl.gexec = nullptr; }
-            hipGraph_t graph = nullptr;
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
-            if (ok) {
-                const int brc = enqueue_body(c, sl, st, false, ROLE_SINGLE, nullptr, true, true);
-                const hipError_t ee = hipStreamEndCapture(st, &graph);
-                ok = brc == SAS_OK && ee == hipSuccess && graph != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&sl.gexec, graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void)hipGraphDestroy(graph);
-            if (!ok) {
-                (void)hipGetLastError();
-                sl.gexec = nullptr;
-                c->use_graphs = false;   // capture unsupported here: stay on the eager path
-            } else {
-                sl.gkey = key;
-            }
-        }
-        if (sl.gexec) {
-            HIP_TRY(c, hipGraphLaunch(sl.gexec, st));
-            HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
-            launched = true;
-        }
-    }
-    if (!launched) {
-        rc = enqueue_body(c, sl, st, timing, role, partner, !early_prologue, false, late_start_wait);
-        if (rc) return rc;
-        HIP_TRY(c, hipGetLastError());
-    }
+    rc = enqueue_body(c, sl, st, timing, role, partner, !early_prologue, late_start_wait);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
     sl.timed = timing;
     sl.timed_tiles = ttiles && !timing && !(a.flags & SAS_FULL_SORT);
     HIP_TRY(c, hipEventRecord(sl.done, st));
@@ -488,11 +431,15 @@ int complete_oldest(sas_ctx *c)
             }
         }
         if (!s[2]) {
-            // later work on the caller's stream is ordered after this frame
+            // Only now -- the host has seen that the frame did not overflow its intersection buffer -- is
+            // later work on the caller's stream ordered behind the frame (the wait is already satisfied: a
+            // no-op on the GPU).  Releasing the caller's stream any earlier would let a stream-ordered
+            // consumer read a truncated frame that is about to be rendered again.
             HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
             sl.busy = false;
             c->head = (c->head + 1) % c->n_slots;
             c->inflight--;
+            c->frames_completed++;
             return SAS_OK;
         }
         // intersection buffer too small: grow to the measured need (+25 %) and render the frame again
@@ -534,9 +481,6 @@ int sas_create(int device, sas_ctx **out)
     if (!c) return SAS_ERR_OOM;
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess;
-    if (const char *e = getenv("SAS_GRAPH")) c->use_graphs = atoi(e) != 0;
-    if (const char *e = getenv("SAS_NO_GRAPH"))
-        if (atoi(e) != 0) c->use_graphs = false;
     if (const char *e = getenv("SAS_SLOTS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= kMaxSlots) c->n_slots = v;
@@ -579,7 +523,6 @@ int sas_destroy(sas_ctx *c)
         for (auto &e : sl.sort_streams.join)
             if (e) (void)hipEventDestroy(e);
         if (sl.fs) (void)hipStreamDestroy(sl.fs);
-        if (sl.gexec) (void)hipGraphExecDestroy(sl.gexec);
         if (sl.stats_host) (void)hipHostFree(sl.stats_host);
         if (sl.params_host) (void)hipHostFree(sl.params_host);
         release(sl.params_dev);
@@ -714,9 +657,7 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
     }
     c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
     // No frame is in flight here.  The poses go into a pinned staging block that every frame copies
-    // to the device on its own stream (a node of its captured graph, re-read at each replay) -- like
-    // the per-frame parameter block.  A host-to-device copy from pageable memory issued here, between
-    // two replays of a frame graph, ended in GPU write faults on ROCm 7.2.
+    // to the device on its own stream, like the per-frame parameter block.
     memcpy(c->groups_pinned, Rt, sizeof(float) * 12 * n_groups);
     return SAS_OK;
 }
@@ -790,15 +731,8 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
         const int role = n == 1 ? ROLE_SINGLE : (k == 0 ? ROLE_LEADER : ROLE_FOLLOWER);
         int rc = enqueue_frame(c, *sl[k], role, n == 2 ? sl[1 - k] : nullptr);
         if (rc) return rc;
-        // Work the caller enqueues on `stream` from now on is ordered behind the PREVIOUS frame (a
-        // stream wait, no host synchronisation): a consumer can run one frame behind the renderer
-        // while this frame overlaps the previous one on the GPU.
-        if (c->inflight > 0) {
-            const int si = (int)(sl[k] - c->slots);
-            Slot &prev = c->slots[(si + c->n_slots - 1) % c->n_slots];
-            if (prev.busy) HIP_TRY(c, hipStreamWaitEvent(st, prev.done, 0));
-        }
         c->inflight++;
+        c->frames_submitted++;
         c->last_slot = (int)(sl[k] - c->slots);
     }
     if (flags & SAS_ASYNC) return SAS_OK;
@@ -860,6 +794,14 @@ int sas_wait(sas_ctx *c)
     if (c->inflight <= 0) return SAS_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     return complete_all(c);
+}
+
+int sas_frames_completed(sas_ctx *c, int64_t *submitted, int64_t *completed)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (submitted) *submitted = c->frames_submitted;
+    if (completed) *completed = c->frames_completed;
+    return SAS_OK;
 }
 
 int sas_stage_times(sas_ctx *c, float *ms, int n)

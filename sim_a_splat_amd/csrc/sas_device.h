@@ -21,23 +21,8 @@ DEV float4 nt_load(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// ---- contract transcendental functions (mirror sas_oracle_expf / sas_oracle_logf) -------------
-DEV float c_expf(float x)
-{
-    float t = x * 1.4426950408889634f;
-    t = fmaxf(t, -125.0f);
-    t = fminf(t, 126.0f);
-    float n = __builtin_rintf(t);
-    float f = t - n;
-    float p = 0.0013400432653725147f;
-    p = fma_(p, f, 0.009676037356257439f);
-    p = fma_(p, f, 0.05550327152013779f);
-    p = fma_(p, f, 0.2402210682630539f);
-    p = fma_(p, f, 0.6931471824645996f);
-    p = fma_(p, f, 1.0000001192092896f);
-    return __builtin_ldexpf(p, (int)n);
-}
-
+// ---- contract logarithm (mirrors sas_oracle_logf; the contract exponential lives with its only
+//      user, the compositing loop: c_expf_neg_small in sas_tile.hip) ------------------------------
 DEV float c_logf(float x)
 {
     unsigned u = __float_as_uint(x);

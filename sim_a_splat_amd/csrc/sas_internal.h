@@ -69,8 +69,8 @@ struct SasOutputs {
     int use_max_depth;
 };
 
-// Per-frame parameters, resident in device memory (one block per frame slot) so that a captured
-// hipGraph of the frame can be replayed with new poses / output buffers without touching its nodes.
+// Per-frame parameters, resident in device memory (one block per frame slot, uploaded on the frame's
+// own stream ahead of its kernels).
 struct SasParams {
     SasCam cam;
     SasOutputs out;

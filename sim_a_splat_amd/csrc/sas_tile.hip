@@ -17,8 +17,6 @@
 
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
-
 #pragma clang fp contract(off)
 
 namespace {
@@ -347,46 +345,6 @@ __global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *perm, c
 // ================================================================================================
 // Compositing
 // ================================================================================================
-
-// Minimum of sigma(dx,dy) = 0.5 (A dx^2 + C dy^2) + B dx dy over a rectangle of pixel centres.
-// A convex quadratic whose centre lies outside the rectangle attains its minimum on an edge.
-DEV float min_sigma_rect(float mx, float my, float A, float B, float C, float nBoverC, float nBoverA,
-                         float xa, float xb, float ya, float yb)
-{
-    const float dxl = mx - xb, dxh = mx - xa, dyl = my - yb, dyh = my - ya;
-    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float dx = e ? dxh : dxl;
-        const float dy = fminf(fmaxf(nBoverC * dx, dyl), dyh);
-        best = fminf(best, 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy);
-        const float ey = e ? dyh : dyl;
-        const float ex = fminf(fmaxf(nBoverA * ey, dxl), dxh);
-        best = fminf(best, 0.5f * (A * ex * ex + C * ey * ey) + B * ex * ey);
-    }
-    return best;
-}
-
-// 4-bit mask of the 8x8 quadrants of tile (tx,ty) that the Gaussian can reach.  Bit q = qx + 2 qy.
-// Computed by the thread that stages the record (one entry per thread, no divergence).
-// A quadrant is dropped only when sigma exceeds the blend loop's skip threshold by a margin
-// (0.05) four orders of magnitude above any rounding difference between this estimate and the
-// contract's per-pixel sigma, so dropping it never changes a pixel.
-DEV unsigned quadrant_mask(int tx, int ty, float mx, float my, float A, float B, float C, float thr)
-{
-    // approximate reciprocals are fine: conservative by the margin
-    const float nBoverC = -B * __builtin_amdgcn_rcpf(C), nBoverA = -B * __builtin_amdgcn_rcpf(A);
-    unsigned m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float xa = (float)(tx * SAS_TILE + (q & 1) * 8) + 0.5f;
-        const float ya = (float)(ty * SAS_TILE + (q >> 1) * 8) + 0.5f;
-        const float ms = min_sigma_rect(mx, my, A, B, C, nBoverC, nBoverA, xa, xa + 7.0f, ya, ya + 7.0f);
-        if (!(ms > thr + 0.05f)) m |= 1u << q;
-    }
-    return m;
-}
 
 // 16-bit mask of the 4x4-pixel blocks of tile (tx,ty) the Gaussian can reach.  Bit = cx + 4 cy.
 // sqrt(sigma) is a seminorm N (the conic is positive semi-definite), so for a pixel p of a block
@@ -801,8 +759,14 @@ constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
 __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC))) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
-                                                             const int *perm, int ablate)
+                                                             const int *perm)
 {
+    // timing experiments only (-DSAS_TUNE_ABLATE=1: no chunk sort, =2: no compositing): wrong images
+#ifdef SAS_TUNE_ABLATE
+    constexpr int ablate = SAS_TUNE_ABLATE;
+#else
+    constexpr int ablate = 0;
+#endif
     // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
     __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 21 KiB
@@ -974,7 +938,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
             const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
             // ---- order the chunk, then composite it
             if (!(ablate & 1)) lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
-            bool all_done = true;   // ablation (debug, SAS_ABLATE): pretend the first chunk saturates
+            bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
                 all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, m,
                                                  [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
@@ -1112,12 +1076,12 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 // Production path: lazy ordering + compositing of every tile in one launch.
 template <bool FAST, bool WMAX>
 static void launch_lazy(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *perm,
-                        int ablate, hipEvent_t e0, hipEvent_t e1)
+                        hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
-        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm, ablate);
+        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm);
     else
-        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm, ablate);
+        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm);
 }
 
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
@@ -1125,13 +1089,12 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
 {
     const unsigned grid = (unsigned)tiles;
     const long long n = s.n > 0 ? s.n : 1;
-    static const int ablate = getenv("SAS_ABLATE") ? atoi(getenv("SAS_ABLATE")) : 0;   // timing experiments only
     if (fast_exp) {
-        if (want_max) launch_lazy<true, true>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
-        else launch_lazy<true, false>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
+        if (want_max) launch_lazy<true, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
     } else {
-        if (want_max) launch_lazy<false, true>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
-        else launch_lazy<false, false>(st, grid, P, f, n, s.perm, ablate, ev_start, ev_stop);
+        if (want_max) launch_lazy<false, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
     }
 }
 

@@ -73,16 +73,102 @@ class FrameGather:
         return self._bufs if self.rank == self.dst else None
 
 
+class StepPipeline:
+    """Render steps asynchronously into a ring of output buffers and gather each step's frames to
+    rank 0 as soon as the renderer reports the step complete (bench.py's loop; the CPU tests drive it
+    with a stand-in renderer over gloo).
+
+    ``submit(i, buf)`` enqueues step ``i`` into ``buf``; ``steps_completed()`` is the number of leading
+    steps whose frames are final (``Rasterizer.frames_completed`` // views per step: only completed
+    frames may be consumed, include/sim_a_splat_amd.h SAS_ASYNC); ``wait()`` completes every submitted
+    step.  ``payload(buf)`` picks the tensor that travels (the uint8 frames).  One gather is in flight
+    at a time, so the xGMI transfer of step g overlaps the rendering of the steps after it.  A buffer
+    is handed to a new step only after the gather that reads it has finished.
+    """
+
+    def __init__(self, world: int, rank: int, buffers: Sequence, submit, steps_completed, wait, payload=lambda b: b,
+                 on_gathered=None):
+        if len(buffers) < 2:
+            raise ValueError("need at least two buffers")
+        self.world, self.rank = world, rank
+        self.bufs = list(buffers)
+        self._submit, self._completed, self._wait, self._payload = submit, steps_completed, wait, payload
+        self._on_gathered = on_gathered
+        self.gather = FrameGather(world, rank)
+        self.base = 0          # steps_completed() at the start of this run
+        self.submitted = 0     # steps submitted in this run
+        self.gathered = 0      # steps whose gather has been started
+        self._reading: Optional[int] = None   # step whose gather may still be reading its buffer
+
+    def begin(self) -> None:
+        self.base = self._completed()
+        self.submitted = self.gathered = 0
+        self._reading = None
+
+    def _finish_gather(self) -> None:
+        got = self.gather.finish()
+        if self._reading is not None and self._on_gathered is not None and self.world > 1:
+            self._on_gathered(self._reading, got)
+        self._reading = None
+
+    def _start_gathers(self, upto: int) -> None:
+        while self.gathered < upto:
+            if self.world > 1:
+                self._finish_gather()
+                self.gather.start(self._payload(self.bufs[self.gathered % len(self.bufs)]))
+                self._reading = self.gathered
+            self.gathered += 1
+
+    def step(self) -> int:
+        i, R = self.submitted, len(self.bufs)
+        if i - self.gathered >= R:            # the ring is full of ungathered steps: complete them first
+            self._wait()
+            self._start_gathers(i)
+        if self._reading is not None and self._reading % R == i % R:
+            self._finish_gather()             # that buffer is about to be overwritten
+        self._submit(i, self.bufs[i % R])
+        self.submitted += 1
+        self._start_gathers(min(self._completed() - self.base, self.submitted))
+        return i
+
+    def drain(self) -> None:
+        """Complete every submitted step and gather what is left."""
+        self._wait()
+        self._start_gathers(self.submitted)
+        if self.world > 1:
+            self._finish_gather()
+
+
+def frame_meta(frames: Sequence[torch.Tensor], rank: int, world: int, src: int = 0):
+    """(shape, dtype) of the frames being gathered, agreed over all ranks: a rank that owns no view
+    (n_views < world) has no frame to read them from, so rank ``src`` (which always owns view 0)
+    broadcasts them."""
+    meta = [None]
+    if rank == src:
+        if not frames:
+            raise ValueError("the source rank owns view 0 and must pass its frame")
+        meta = [(tuple(frames[0].shape), frames[0].dtype)]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=src)
+    return meta[0]
+
+
 def gather_frames(frames: Sequence[torch.Tensor], n_views: int, rank: int, world: int) -> Optional[List[torch.Tensor]]:
-    """Synchronous helper: every rank passes the frames of its ``shard_views`` views (same shape);
-    rank 0 gets the list of all ``n_views`` frames in view order."""
+    """Synchronous helper: every rank passes the frames of its ``shard_views`` views (same shape; a
+    rank without views passes an empty list); rank 0 gets the list of all ``n_views`` frames in view
+    order."""
     if world <= 1:
         return list(frames)
+    shape, dtype = frame_meta(frames, rank, world)
+    if frames:
+        device = frames[0].device
+    else:   # RCCL gathers device tensors, gloo host tensors
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     rounds = (n_views + world - 1) // world
     out: List[Optional[torch.Tensor]] = [None] * n_views
     g = FrameGather(world, rank)
     for r in range(rounds):
-        mine = frames[r] if r < len(frames) else torch.zeros_like(frames[0])
+        mine = frames[r] if r < len(frames) else torch.zeros(shape, dtype=dtype, device=device)
         g.start(mine)
         got = g.finish()
         if rank == 0:

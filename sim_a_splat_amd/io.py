@@ -39,13 +39,16 @@ CKPT_PREFIX = "_model.gauss_params."
 CKPT_FIELDS = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
 
 
-def load_splatfacto_ckpt(path) -> Dict[str, np.ndarray]:
-    """``gauss_params`` of a nerfstudio 1.1.x splatfacto checkpoint (``pipeline`` state dict)."""
+def load_splatfacto_ckpt(path, trust_pickle: bool = False) -> Dict[str, np.ndarray]:
+    """``gauss_params`` of a nerfstudio 1.1.x splatfacto checkpoint (``pipeline`` state dict).
+
+    Loaded with ``weights_only=True`` (tensors and primitives only: nothing in the file is executed).
+    ``trust_pickle=True`` is the explicit opt-in for a checkpoint that needs the full unpickler."""
     import torch
     p = Path(path)
     if p.stat().st_size < 1024 and p.read_bytes().startswith(b"version https://git-lfs"):
         raise FileNotFoundError(f"{path} is a Git-LFS pointer, not a checkpoint")
-    sd = torch.load(p, map_location="cpu", weights_only=False)
+    sd = torch.load(p, map_location="cpu", weights_only=not trust_pickle)
     sd = sd.get("pipeline", sd)
     out = {}
     for f in CKPT_FIELDS:

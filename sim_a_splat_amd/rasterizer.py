@@ -55,7 +55,7 @@ class Rasterizer:
             raise SasError(f"sas_create(device={self.device.index}) failed with status {rc}")
         self.n = 0
         self.n_groups = 0
-        self._keep = []  # outputs of in-flight async frames (the C ABI keeps up to two)
+        self._keep = []  # outputs of in-flight async frames (the C ABI keeps up to four)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -137,9 +137,10 @@ class Rasterizer:
         """Render one view; returns device tensors ``rgb [H,W,3]``, ``alpha [H,W,1]``,
         ``depth [H,W,1]`` (float32) and/or ``rgb8 [H,W,3]`` (uint8) as listed in ``want``.
 
-        ``block=False`` only enqueues (SAS_ASYNC): up to four frames are in flight, the result of a
-        frame is valid after ``wait()``; work enqueued on the current stream after ``render`` of frame
-        i returns is ordered behind frame i-1.  ``full_sort=True`` orders every tile list
+        ``block=False`` only enqueues (SAS_ASYNC): up to four frames are in flight.  Frames complete in
+        submission order inside later ``render*`` calls or ``wait()``; a frame's outputs may be consumed
+        (and work on the current stream is ordered behind it) only once it is complete --
+        ``frames_completed()`` tells how many are.  ``full_sort=True`` orders every tile list
         completely and keeps it for ``read_tile_lists`` (same image, slower)."""
         V = self._host_f32(viewmat, 16)
         Kc = self._host_f32(K, 9)
@@ -231,6 +232,13 @@ class Rasterizer:
     def wait(self) -> None:
         self._check(self._L.sas_wait(self._ctx), "sas_wait")
         self._keep = []
+
+    def frames_completed(self) -> Tuple[int, int]:
+        """(submitted, completed) frame counts since creation (sas_frames_completed): frames
+        ``0 .. completed-1`` are final and the current stream is ordered behind them."""
+        sub, com = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.sas_frames_completed(self._ctx, ctypes.byref(sub), ctypes.byref(com)), "sas_frames_completed")
+        return int(sub.value), int(com.value)
 
     # -- introspection ------------------------------------------------------------------------
     def stage_times(self) -> Dict[str, float]:

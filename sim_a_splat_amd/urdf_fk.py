@@ -3,9 +3,22 @@
 ``SplatHandler._add_robot_meshes`` (sim_a_splat/splat/splat_handler.py:147-200) loads the URDF with
 urchin, evaluates ``visual_trimesh_fk(cfg=dict(zip(actuated_joint_names, joint_config)))`` and keeps
 one SE3 per visual mesh (``fk_tf``, :197); ``draw_handler`` uses them as ``Rfk, tfk`` (:262-278).
-This module restates that computation without urchin/trimesh: it parses the URDF XML, orders the
-actuated joints base-outwards, and returns ``link_pose @ visual.origin [@ diag(mesh scale)]`` for every
-visual that has a mesh, links in file order.
+This module restates that computation without urchin/trimesh: it parses the URDF XML and returns
+``link_pose @ visual.origin [@ diag(mesh scale)]`` for every visual that has a mesh.
+
+Orders follow urchin 0.0.29 / networkx 3.5 (``pixi.lock:268,199``; neither is vendored, restated from
+their published source) because the reference indexes both lists by position
+(``fk_tf[i]``, ``dict(zip(actuated_joint_names, joint_config))``):
+
+* links: urchin builds a DiGraph with the links as nodes (file order) and one edge child -> parent per
+  joint, and walks ``reversed(list(nx.topological_sort(G)))``; networkx emits topological *generations*
+  (Kahn's algorithm, nodes of a generation in insertion order), so the order is by height above the
+  leaves, not by depth below the base -- it coincides with file order for a serial chain such as the
+  xarm6 and differs for branching robots (grippers) and links declared out of order;
+* actuated joints: sorted by the number of links on the child's path to the base (``_sort_joints``,
+  ``np.argsort`` of small arrays: ties keep file order);
+* one pose per mesh of a visual: mesh files are not opened here, so a visual counts as ONE mesh
+  (multi-mesh files, e.g. a .dae scene, would need the file; ``meshes_per_visual`` lets a caller say so).
 """
 from __future__ import annotations
 
@@ -85,6 +98,7 @@ class Robot:
     joints: List[Joint]
     base: str = ""
     actuated_joints: List[Joint] = field(default_factory=list)
+    fk_link_order: List[str] = field(default_factory=list)   # urchin's link_fk / visual_trimesh_fk order
 
     @property
     def actuated_joint_names(self) -> List[str]:
@@ -117,22 +131,38 @@ def load(urdf: Union[str, Path]) -> Robot:
     if len(bases) != 1:
         raise ValueError(f"URDF must have exactly one base link, found {bases}")
     rb = Robot(links, visuals, joints, base=bases[0])
-    # actuated joints base-outwards (breadth first from the base link, ties in file order)
-    by_parent: Dict[str, List[Joint]] = {}
+    parent_joint = {j.child: j for j in joints}
+    if len(parent_joint) != len(joints):
+        raise ValueError("a link is the child of two joints")
+    depth: Dict[str, int] = {}
+    for l in links:                               # links on the path to the base, the link itself included
+        d, cur, seen = 1, l, set()
+        while cur != rb.base:
+            if cur in seen or cur not in parent_joint:
+                raise ValueError("URDF joints do not form a tree rooted at the base link")
+            seen.add(cur)
+            cur = parent_joint[cur].parent
+            d += 1
+        depth[l] = d
+    # evaluation order for link_fk: any base-outwards order (parents before children)
+    rb.joints = [j for _, _, j in sorted(((depth[j.child], k, j) for k, j in enumerate(joints)), key=lambda t: t[:2])]
+    # urchin: actuated joints in file order, stably sorted by the child's path length to the base
+    rb.actuated_joints = [j for j in rb.joints if j.type in ACTUATED and j.mimic is None]
+    # urchin / networkx: reversed topological generations of the child -> parent graph
+    indeg = {l: 0 for l in links}
     for j in joints:
-        by_parent.setdefault(j.parent, []).append(j)
-    frontier, ordered = [rb.base], []
-    while frontier:
-        nxt = []
-        for l in frontier:
-            for j in by_parent.get(l, []):
-                ordered.append(j)
-                nxt.append(j.child)
-        frontier = nxt
-    if len(ordered) != len(joints):
-        raise ValueError("URDF joints do not form a tree rooted at the base link")
-    rb.joints = ordered
-    rb.actuated_joints = [j for j in ordered if j.type in ACTUATED and j.mimic is None]
+        indeg[j.parent] += 1
+    zero, topo = [l for l in links if indeg[l] == 0], []
+    while zero:
+        gen, zero = zero, []
+        for l in gen:
+            topo.append(l)
+            if l in parent_joint:
+                p = parent_joint[l].parent
+                indeg[p] -= 1
+                if indeg[p] == 0:
+                    zero.append(p)
+    rb.fk_link_order = topo[::-1]
     return rb
 
 
@@ -156,11 +186,13 @@ def link_fk(robot: Robot, cfg: Union[Dict[str, float], Sequence[float], None] = 
     return poses
 
 
-def visual_mesh_fk(robot: Robot, cfg=None) -> List[np.ndarray]:
-    """One 4x4 per visual mesh, links in file order (the ``fk_tf`` list of splat_handler.py:197)."""
+def visual_mesh_fk(robot: Robot, cfg=None, meshes_per_visual: Optional[Dict[str, int]] = None) -> List[np.ndarray]:
+    """One 4x4 per visual mesh in urchin's order (the ``fk_tf`` list of splat_handler.py:197): links in
+    ``robot.fk_link_order``, a link's visuals in file order.  ``meshes_per_visual`` maps a mesh filename
+    to the number of meshes the file holds (urchin emits one entry per mesh; default 1)."""
     poses = link_fk(robot, cfg)
     out = []
-    for l in robot.links:
+    for l in robot.fk_link_order or robot.links:
         for v in robot.visuals[l]:
             if v.mesh is None:
                 continue
@@ -169,5 +201,5 @@ def visual_mesh_fk(robot: Robot, cfg=None) -> List[np.ndarray]:
                 S = np.eye(4)
                 S[:3, :3] = np.diag(v.scale)
                 T = T @ S
-            out.append(T)
+            out.extend([T] * int((meshes_per_visual or {}).get(v.mesh, 1)))
     return out

@@ -37,8 +37,10 @@ def _worker(rank, world, port, n_views, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [2, 5])
+@pytest.mark.parametrize("n_views", [1, 2, 5])
 def test_shard_and_gather_two_ranks(n_views):
+    """n_views = 1: rank 1 owns no view (the reference's 2 cameras over 8 GPUs, in small) and must still
+    take part in the gather instead of raising and leaving rank 0 blocked."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -59,3 +61,92 @@ def test_shard_views_partition():
             parts = [sdist.shard_views(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+class _FakeRenderer:
+    """Stand-in for the asynchronous rasterizer: a step's frames become final `lag` submissions later
+    (or at wait()), exactly as frames complete inside later sas_render* calls.  Until then the buffer
+    holds garbage; it also records any write into a buffer a gather might still be reading."""
+
+    def __init__(self, rank, lag):
+        self.rank, self.lag = rank, lag
+        self.pending = []          # (step, buf)
+        self.completed = 0
+        self.reading = {}          # id(buf) -> step being gathered
+        self.violations = []
+
+    def value(self, step):
+        return float(100 * step + self.rank)
+
+    def submit(self, i, buf):
+        if id(buf) in self.reading:
+            self.violations.append(("overwrite while gathering", i, self.reading[id(buf)]))
+        buf.fill_(-1.0)            # a truncated / in-flight frame
+        self.pending.append((i, buf))
+        while len(self.pending) > self.lag:
+            self._complete_one()
+
+    def _complete_one(self):
+        i, buf = self.pending.pop(0)
+        buf.fill_(self.value(i))
+        self.completed += 1
+
+    def steps_completed(self):
+        return self.completed
+
+    def wait(self):
+        while self.pending:
+            self._complete_one()
+
+
+def _pipeline_worker(rank, world, port, n_steps, lag, n_bufs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    fake = _FakeRenderer(r, lag)
+    bufs = [torch.zeros((3, 5)) for _ in range(n_bufs)]
+    seen = []
+
+    def on_gathered(step, got):
+        fake.reading = {}
+        if r == 0:
+            seen.append((step, [float(t[0, 0].item()) for t in got]))
+
+    pipe = sdist.StepPipeline(w, r, bufs, fake.submit, fake.steps_completed, fake.wait, on_gathered=on_gathered)
+    orig_start = pipe.gather.start
+
+    def start(frame):
+        orig_start(frame)
+        fake.reading = {id(b): pipe.gathered for b in bufs if b is frame}
+    pipe.gather.start = start
+    for rnd in range(2):           # warm-up run, then the timed run: bench.py calls begin() twice
+        pipe.begin()
+        for _ in range(n_steps):
+            pipe.step()
+        pipe.drain()
+    if r == 0:
+        q.put((seen, fake.violations))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lag,n_bufs", [(2, 4), (1, 2), (3, 3)])
+def test_step_pipeline_gathers_only_completed_steps(lag, n_bufs):
+    """bench.py's buffer rotation and lagging gather, driven over gloo by a stand-in renderer whose
+    frames become final `lag` steps after submission: rank 0 must receive every step exactly once, in
+    order, with the FINAL values of both ranks, and no buffer may be handed to a new step while the
+    gather that reads it is in flight -- also when the ring is smaller than the completion lag."""
+    n_steps = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, n_steps, lag, n_bufs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen, violations = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert violations == []
+    want = [(s, [100.0 * s, 100.0 * s + 1.0]) for s in range(n_steps)] * 2
+    assert seen == want

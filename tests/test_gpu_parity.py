@@ -362,28 +362,34 @@ def test_view_pairs_equal_single_views(monkeypatch):
     for i in range(3):
         for k in ("rgb", "alpha", "depth", "rgb8"):
             assert torch.equal(batch[k][i], singles[i][k]), (i, k)
-    # asynchronous pairs: work on the caller's stream after the call is ordered behind the previous batch
-    outs = [{"rgb": torch.empty((2, 200, 300, 3), device="cuda:0")} for _ in range(3)]
-    snaps = []
-    for j in range(3):
+    # asynchronous pairs: work on the caller's stream is ordered behind every COMPLETED frame
+    outs = [{"rgb": torch.empty((2, 200, 300, 3), device="cuda:0")} for _ in range(5)]
+    snaps, taken = [], 0
+    base = rasterizer.frames_completed()[1]
+    for j in range(5):
         rasterizer.render_batch(Vs[[0, 2]], Ks[[0, 2]], 300, 200, BG, want=("rgb",), out=outs[j], block=False)
-        if j > 0:
-            snaps.append(outs[j - 1]["rgb"].clone())
+        done_batches = (rasterizer.frames_completed()[1] - base) // 2
+        while taken < done_batches:
+            snaps.append(outs[taken]["rgb"].clone())   # stream-ordered consumer, no host synchronisation
+            taken += 1
+    assert 1 <= taken < 5                              # four slots: batches complete while later ones are in flight
     rasterizer.wait()
+    sub, com = rasterizer.frames_completed()
+    assert sub == com == base + 10
     for sn in snaps + [o["rgb"] for o in outs]:
         assert torch.equal(sn[0], singles[0]["rgb"]) and torch.equal(sn[1], singles[2]["rgb"])
     rasterizer.close()
 
 
-def test_group_pose_updates_between_graph_replays(rasterizer):
-    """Regression: per-step set_group_poses between replays of the captured frame graphs (the Gym loop:
-    poses, then one blocking render per camera) -- once a GPU write fault when the poses were copied
-    from pageable memory between two replays.  Frames follow the poses of their step."""
+def test_group_pose_updates_between_frames(rasterizer):
+    """Per-step set_group_poses between frames (the Gym loop: poses, then one blocking render per camera):
+    the poses travel through a pinned staging block on each frame's own stream, and every frame slot is
+    reused several times.  Frames follow the poses of their step."""
     sc = make_scene(20000, seed=333, log_scale_mean=float(np.log(0.03)), n_groups=5)
     _upload(rasterizer, sc, group_id=sc.group_id, n_groups=5)
     cams = [ring_camera(160, 120, 130.0, yaw_deg=0.0), ring_camera(160, 120, 130.0, yaw_deg=70.0, elev=0.4)]
     last = None
-    for step in range(12):                       # every frame slot captures once and replays several times
+    for step in range(12):                       # every frame slot is used several times
         Rt = random_group_poses(5, seed=step)
         rasterizer.set_group_poses(Rt)
         last = [rasterizer.render(c.viewmat, c.K, 160, 120, BG, want=("rgb8", "rgb"))["rgb"].cpu().numpy() for c in cams]
@@ -394,7 +400,7 @@ def test_group_pose_updates_between_graph_replays(rasterizer):
 
 
 def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch):
-    """More intersections than the initial buffer holds (max(4 N, 2^20) keys): the frame is detected as
+    """More intersections than the initial buffer holds (max(8 N, 2^20) keys): the frame is detected as
     overflowed from its stats, the buffer grows to the measured need and the frame is rendered again --
     for a blocking single view, and for both views of an asynchronous pair."""
     import torch
@@ -419,6 +425,38 @@ def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch):
     assert r.stats()["regrows"] >= 2
     for v in range(2):
         assert np.array_equal(out["rgb"][v].cpu().numpy(), refs[v]["rgb"]), v
+    r.close()
+
+
+def test_stream_ordered_consumer_of_overflowing_async_frames():
+    """An asynchronous sequence whose every frame slot overflows its intersection buffer on first use:
+    a consumer on the caller's stream (a device-side copy, no host synchronisation) that takes each
+    frame as soon as sas_frames_completed reports it must see the final frame, never the truncated
+    first attempt, and the re-render must not race with it."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    r = Rasterizer("cuda:0")
+    sc = make_scene(30000, seed=444, log_scale_mean=float(np.log(0.12)))
+    _upload(r, sc)
+    cams = [ring_camera(640, 480, 500.0, yaw_deg=90.0 * (k % 2)) for k in range(7)]
+    refs = [oracle.render_scene(sc, c, background=BG) for c in cams[:2]]
+    assert min(ref["n_isect"] for ref in refs) > (1 << 20)
+    outs = [torch.empty((480, 640, 3), device="cuda:0") for _ in cams]
+    copies, taken = [], 0
+    for k, c in enumerate(cams):
+        r.render(c.viewmat, c.K, 640, 480, BG, want=("rgb",), out={"rgb": outs[k]}, block=False)
+        while taken < r.frames_completed()[1]:
+            copies.append(outs[taken].clone())
+            outs[taken].zero_()                        # the consumer owns the buffer from here on
+            taken += 1
+    assert 1 <= taken < len(cams)
+    r.wait()
+    while taken < len(cams):
+        copies.append(outs[taken].clone())
+        taken += 1
+    assert r.stats()["regrows"] >= 4                   # every slot overflowed once
+    for k, cp in enumerate(copies):
+        assert np.array_equal(cp.cpu().numpy(), refs[k % 2]["rgb"]), k
     r.close()
 
 
