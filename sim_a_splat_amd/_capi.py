@@ -6,11 +6,14 @@ module's ``lib()`` raises.  The oracle under ``oracle/`` is never imported from 
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 from typing import Optional
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libsas_hip.so"
+# SAS_LIB_PATH points the binding at another build of the same library (the -DSAS_TUNE_* / -DSAS_DEBUG_BOUNDS
+# variants under variants/, for A/B measurements and the bounds-checked test run)
+LIB_PATH = Path(os.environ.get("SAS_LIB_PATH") or (_PKG / "libsas_hip.so"))
 
 SAS_DEPTH_FILL_MAX = 1
 SAS_ASYNC = 2

@@ -32,17 +32,20 @@ def up_to_date() -> bool:
     return LIB.exists() and all(LIB.stat().st_mtime >= d.stat().st_mtime for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and up_to_date():
+def build(force: bool = False, verbose: bool = False, out: Path = None, extra_flags=()) -> Path:
+    """Default: the product library in-tree.  ``out`` + ``extra_flags`` build a variant elsewhere
+    (``python -m sim_a_splat_amd.build --variant stats -DSAS_TUNE_STATS`` -> variants/lib_stats.so)."""
+    if out is None and not force and up_to_date():
         return LIB
+    LIB_OUT = Path(out) if out is not None else LIB
     cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
            # the SLP vectorizer pairs scalar f32 ops into v_pk_*_f32 (1.4x the issue cost of a scalar op on
            # gfx950, tools/microbench/pk_f32_rate.hip) plus the moves that assemble their operands: a net
            # loss in the compositing loop (+4.4 % frames/s at config 3 without it)
            "-fno-slp-vectorize",
-           *os.environ.get("SAS_HIPCC_FLAGS", "").split(),   # experiments only
-           "-x", "hip", *map(str, SOURCES), "-o", str(LIB)]
+           *os.environ.get("SAS_HIPCC_FLAGS", "").split(), *extra_flags,   # experiments only
+           "-x", "hip", *map(str, SOURCES), "-o", str(LIB_OUT)]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -50,8 +53,17 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
     if verbose:
         print(res.stderr)
-    return LIB
+    return LIB_OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    args = sys.argv[1:]
+    if "--variant" in args:
+        k = args.index("--variant")
+        name = args[k + 1]
+        flags = [a for a in args[k + 2:] if a != "-v"]
+        vdir = PKG.parent / "variants"
+        vdir.mkdir(exist_ok=True)
+        print(build(force=True, verbose="-v" in args, out=vdir / f"lib_{name}.so", extra_flags=flags))
+    else:
+        print(build(force="--force" in args, verbose="-v" in args))

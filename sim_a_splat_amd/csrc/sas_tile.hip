@@ -407,10 +407,10 @@ DEV PixConst pix_const(int ox, int oy)
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
-// Contract exp for candidate lanes only: -1e-2 < sigma <= thr <= ln(255)+1e-3, so the contract's
-// clamp on the argument is a no-op and is left out (identical bits).  n = round(x log2 e) is read off
-// the low mantissa bits of x log2 e + 1.5 * 2^23 and added straight into the exponent field.
-DEV float c_expf_neg_small(float x, float e5 /* 0.0013400432653725147f, pinned in a register */)
+// Contract exp for an argument the caller has clamped to [-86, rounding noise] (sas_oracle_expf clamps to
+// [-86, 86]; -sigma never comes near the upper end).  n = round(x log2 e) is read off the low mantissa bits
+// of x log2 e + 1.5 * 2^23 and added straight into the exponent field.
+DEV float c_expf_neg(float x, float e5 /* 0.0013400432653725147f, pinned in a register */)
 {
     const float magic = 12582912.0f;
     const float tm = fma_(x, 1.4426950408889634f, magic);
@@ -424,21 +424,6 @@ DEV float c_expf_neg_small(float x, float e5 /* 0.0013400432653725147f, pinned i
     return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tm) << 23));
 }
 
-// Lane selects under an explicit wave mask (SGPR pair): dst = mask[lane] ? b : a.  The compiler
-// otherwise rebuilds lane predicates from bools with extra v_cndmask/v_cmp pairs.
-typedef unsigned long long wmask;
-DEV float sel_mask(float a, float b, wmask m)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
-    return r;
-}
-DEV float sel_mask_or_zero(float b, wmask m)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(b), "s"(m));
-    return r;
-}
 // a constant pinned in a VGPR (the compiler would re-materialise it with a v_mov inside the loop:
 // an SGPR cannot sit beside the literal of v_fmaak on gfx9's one-read constant bus)
 DEV float vgpr_const(unsigned bits)
@@ -610,51 +595,47 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 const float4 H0 = *reinterpret_cast<const float4 *>(q1b + off0);
                 const float4 K1 = *reinterpret_cast<const float4 *>(q0b + off1);
                 const float4 H1 = *reinterpret_cast<const float4 *>(q1b + off1);
+                const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
+                const float4 C1 = *reinterpret_cast<const float4 *>(q2b + off1);
                 const float sg0 = fma_(H0.y, pc.xy, fma_(H0.x, pc.yy, fma_(K0.w, pc.xx, fma_(K0.z, pc.y, fma_(K0.y, p.x, K0.x)))));
                 const float sg1 = fma_(H1.y, pc.xy, fma_(H1.x, pc.yy, fma_(K1.w, pc.xx, fma_(K1.z, pc.y, fma_(K1.y, p.x, K1.x)))));
-                // candidates: sigma <= thr (sigma > thr implies alpha < 1/255 with a margin far above
-                // rounding: the same decision as the contract's alpha test); NaN for a parked pixel
-                const wmask cand0 = __ballot(sg0 <= H0.z);
-                const wmask cand1 = __ballot(sg1 <= H1.z);
+                // Every decision below is a per-lane select on a value, not a wave mask combined on the
+                // scalar unit (which the CU's four SIMDs share: a scalar instruction costs as much issue time
+                // as a vector one).  A lane the splat does not reach has a large sigma: the contract's clamp
+                // of the exponent argument makes its alpha underflow and fail the 1/255 test by itself; a
+                // parked pixel (x = NaN -> sigma = NaN) is clamped the same way (max returns the number).
                 DBG_ADD(0, 2);
-                if (cand0 | cand1) {
-                    DBG_ADD(1, 2);
-                    DBG_ADD(2, __popcll(cand0) + __popcll(cand1));
-                    const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
-                    const float4 C1 = *reinterpret_cast<const float4 *>(q2b + off1);
-                    float E0, E1;
-                    if (FAST_EXP) { E0 = __expf(-sg0); E1 = __expf(-sg1); }
-                    else { E0 = c_expf_neg_small(-sg0, sE5); E1 = c_expf_neg_small(-sg1, sE5); }
-                    const float al0 = fminf(kMaxAlpha, H0.w * E0);
-                    const float al1 = fminf(kMaxAlpha, H1.w * E1);
-                    // first entry: weight w = alpha T, next T = T - w
-                    const wmask keep0 = cand0 & ~__ballot(al0 < kAlphaThr);
-                    const float w0 = al0 * p.T;
-                    const float nT0 = p.T - w0;
-                    const wmask stop0 = keep0 & __ballot(nT0 <= kTStop);   // the splat that ends a pixel is not added
-                    const wmask upd0 = keep0 & ~stop0;
-                    // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
-                    // colours and depths of the path, so one select on the weight replaces four
-                    const float vis0 = sel_mask_or_zero(w0, upd0);
-                    const float Tm = sel_mask(p.T, nT0, upd0);
-                    // second entry: a pixel the first one terminated takes nothing more
-                    const wmask keep1 = cand1 & ~__ballot(al1 < kAlphaThr) & ~stop0;
-                    const float w1 = al1 * Tm;
-                    const float nT1 = Tm - w1;
-                    const wmask stop1 = keep1 & __ballot(nT1 <= kTStop);
-                    const wmask upd1 = keep1 & ~stop1;
-                    DBG_ADD(3, __popcll(upd0) + __popcll(upd1));
-                    const float vis1 = sel_mask_or_zero(w1, upd1);
-                    p.T = sel_mask(Tm, nT1, upd1);
-                    p.r = fma_(C1.x, vis1, fma_(C0.x, vis0, p.r));
-                    p.g = fma_(C1.y, vis1, fma_(C0.y, vis0, p.g));
-                    p.b = fma_(C1.z, vis1, fma_(C0.z, vis0, p.b));
-                    p.d = fma_(C1.w, vis1, fma_(C0.w, vis0, p.d));
-                    const wmask stopm = stop0 | stop1;
-                    if (stopm) {   // rare: some pixel terminated on these splats
-                        p.x = sel_mask(p.x, __builtin_nanf(""), stopm);
-                        if (__all(pix_dead(p))) break;
-                    }
+                float E0, E1;
+                if (FAST_EXP) { E0 = __expf(fmaxf(-sg0, -86.0f)); E1 = __expf(fmaxf(-sg1, -86.0f)); }
+                else { E0 = c_expf_neg(fmaxf(-sg0, -86.0f), sE5); E1 = c_expf_neg(fmaxf(-sg1, -86.0f), sE5); }
+                const float al0 = fminf(kMaxAlpha, H0.w * E0);
+                const float al1 = fminf(kMaxAlpha, H1.w * E1);
+                // first entry: weight w = alpha T (0 when skipped), next T = T - w
+                const float w0 = (al0 < kAlphaThr) ? 0.0f : al0 * p.T;
+                const float nT0 = p.T - w0;
+                const bool stop0 = nT0 <= kTStop;   // the splat that ends a pixel is not added (a live pixel has T > 1e-4, so a skipped splat never stops it)
+                // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
+                // colours and depths of the path, so one select on the weight replaces four
+                const float vis0 = stop0 ? 0.0f : w0;
+                const float Tm = stop0 ? p.T : nT0;
+                // second entry: a pixel the first one terminated takes nothing more
+                const float a1 = stop0 ? 0.0f : al1;
+                const float w1 = (a1 < kAlphaThr) ? 0.0f : a1 * Tm;
+                const float nT1 = Tm - w1;
+                const bool stop1 = nT1 <= kTStop;
+                const float vis1 = stop1 ? 0.0f : w1;
+                p.T = stop1 ? Tm : nT1;
+                p.r = fma_(C1.x, vis1, fma_(C0.x, vis0, p.r));
+                p.g = fma_(C1.y, vis1, fma_(C0.y, vis0, p.g));
+                p.b = fma_(C1.z, vis1, fma_(C0.z, vis0, p.b));
+                p.d = fma_(C1.w, vis1, fma_(C0.w, vis0, p.d));
+#ifdef SAS_TUNE_STATS
+                { const unsigned long long c3 = __popcll(__ballot(vis0 > 0.0f)) + __popcll(__ballot(vis1 > 0.0f)); DBG_ADD(3, c3); }
+#endif
+                const bool stop = stop0 || stop1;
+                if (__any(stop)) {   // rare: some pixel terminated on these splats
+                    if (stop) p.x = __builtin_nanf("");
+                    if (__all(pix_dead(p))) break;
                 }
             }
             wdone = __all(pix_dead(p));

@@ -47,7 +47,7 @@ template <int MODE>
 static void run(const char *name, int insts_per_iter, float *d, int clock_khz, int cus)
 {
     const int iters = 20000;
-    for (int wps = 1; wps <= 4; wps *= 2) {   // waves per SIMD: blocks of 256 threads = 1 wave per SIMD per block
+    for (int wps = 1; wps <= 8; wps *= 2) {   // waves per SIMD: blocks of 256 threads = 1 wave per SIMD per block
         const int blocks = cus * wps;
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
@@ -72,7 +72,7 @@ int main()
     hipGetDeviceProperties(&p, 0);
     printf("%s: %d CUs, %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     float *d;
-    hipMalloc(&d, sizeof(float) * 256 * p.multiProcessorCount * 4);
+    hipMalloc(&d, sizeof(float) * 256 * p.multiProcessorCount * 8);
     run<0>("v_fma_f32", 16, d, p.clockRate, p.multiProcessorCount);
     run<1>("v_pk_fma_f32", 8, d, p.clockRate, p.multiProcessorCount);
     run<2>("v_pk_mul_f32", 8, d, p.clockRate, p.multiProcessorCount);
