@@ -21,6 +21,8 @@
 
 namespace {
 
+constexpr int kSortThreads = 256;   // workgroup size of the lazy tile kernel (lds_bucket_rank_sort)
+
 DEV unsigned hi32(unsigned long long k) { return (unsigned)(k >> 32); }
 DEV unsigned *s_queue_u32(unsigned char *raw) { return reinterpret_cast<unsigned *>(raw); }   // scratch words in a free LDS region
 DEV unsigned lo32(unsigned long long k) { return (unsigned)k; }
@@ -129,6 +131,45 @@ DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int
             }
         }
     }
+    __syncthreads();
+}
+
+// Order a chunk whose keys are already grouped by depth bucket (bucket b occupies [cur[b] - hist[b], cur[b])
+// of buf; key = depth word relative to the chunk's base << 32 | storage slot): every key counts the keys of
+// its own bucket that precede it in the reference order (depth word, then the caller's index perm[slot]) and
+// moves to bucket start + count.  Buckets hold a handful of keys (256 buckets over the tile's depth range), so
+// this is a few compares per key and three barriers, against three 4-barrier passes of the radix sort.
+template <int NK>
+DEV void lds_bucket_rank_sort(unsigned long long *buf, int m, int b0, int shift, const unsigned *hist, const unsigned *cur,
+                              const int *perm)
+{
+    const int tid = threadIdx.x;
+    unsigned long long key[NK];
+    int dst[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        const int i = u * kSortThreads + tid;
+        dst[u] = -1;
+        if (i < m) {
+            key[u] = buf[i];
+            const unsigned hk = hi32(key[u]);
+            const int b = b0 + (int)(hk >> shift);
+            const int en = (int)cur[b], st = en - (int)hist[b];
+            int rank = 0;
+            for (int j = st; j < en; ++j) {
+                const unsigned long long kj = buf[j];
+                const unsigned hj = hi32(kj);
+                bool less = hj < hk;
+                if (hj == hk && j != i) less = perm[lo32(kj)] < perm[lo32(key[u])];   // identical depth words: rare
+                rank += less ? 1 : 0;
+            }
+            dst[u] = st + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+        if (dst[u] >= 0) buf[dst[u]] = key[u];
     __syncthreads();
 }
 
@@ -569,6 +610,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             int qn[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (64 * j >= cnt) break;   // partial batch (uniform)
                 const int e = j * 64 + lane;
                 const unsigned me = e < cnt ? L.mask[e] : 0u;
 #pragma unroll
@@ -632,9 +674,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #ifdef SAS_TUNE_STATS
                 { const unsigned long long c3 = __popcll(__ballot(vis0 > 0.0f)) + __popcll(__ballot(vis1 > 0.0f)); DBG_ADD(3, c3); }
 #endif
-                const bool stop = stop0 || stop1;
-                if (__any(stop)) {   // rare: some pixel terminated on these splats
-                    if (stop) p.x = __builtin_nanf("");
+                if (__ballot(stop0) | __ballot(stop1)) {   // rare: some pixel terminated on these splats
+                    if (stop0 || stop1) p.x = __builtin_nanf("");
                     if (__all(pix_dead(p))) break;
                 }
             }
@@ -736,6 +777,10 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 #define SAS_TUNE_U 8
 #endif
 constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per round
+#ifndef SAS_TUNE_RANKMAX
+#define SAS_TUNE_RANKMAX 48
+#endif
+constexpr int kRankMax = SAS_TUNE_RANKMAX;   // largest depth bucket a chunk is ordered by counting (else radix passes)
 constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
@@ -752,6 +797,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
     __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 21 KiB
     __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_cur[256];   // per-bucket write cursor of the chunk being collected
     __shared__ unsigned s_wsum[4], s_wmax[4];
     __shared__ unsigned s_mn, s_mx, s_m;
     __shared__ int s_b1;
@@ -849,6 +895,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
         for (;;) {
             // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
             //      whose running count from b0 stays <= kChunk.  Thread t owns bucket t.
+            unsigned my_hv, my_incl;
             {
                 const unsigned hv = (tid >= b_next) ? s_hist[tid] : 0u;
                 unsigned incl = hv;
@@ -860,6 +907,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
                 if (lane == 63) s_wsum[wv] = incl;
                 __syncthreads();
                 for (int w = 0; w < wv; ++w) incl += s_wsum[w];        // inclusive count of buckets b_next..tid
+                my_hv = hv;
+                my_incl = incl;
                 const unsigned long long nz = __ballot(hv != 0u);
                 const unsigned long long fit = __ballot(hv != 0u && incl <= (unsigned)kChunk);
                 if (lane == 0) {
@@ -884,10 +933,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
             __syncthreads();
             if (b1 == 256) break;                 // nothing left
             if (b1 < 0) { bail = true; break; }   // one bucket larger than the chunk: full path
-            // ---- collect the range into LDS, depth words relative to the range's base
+            // ---- collect the range into LDS grouped by bucket (bucket t starts at the exclusive count of
+            //      the buckets before it), depth words relative to the range's base
             const unsigned base = dmin + ((unsigned)b0 << shift);
-            if (tid == 0) s_m = 0u;
-            __syncthreads();
+            const bool mine = tid >= b0 && tid <= b1;
+            if (mine) s_cur[tid] = my_incl - my_hv;
+            if (tid == b1) s_m = my_incl;                            // entries in the chunk
+            const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
             for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
                 unsigned long long kk[U];
 #pragma unroll
@@ -897,28 +949,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    // wave-aggregated append: one LDS atomic per wave instead of 64 on one address
-                    bool sel = false;
                     if (i0 + u * kLazyThreads + tid < n) {
                         const int b = (int)((hi32(kk[u]) - dmin) >> shift);
-                        sel = b >= b0 && b <= b1;
-                    }
-                    const unsigned long long sm = __ballot(sel);
-                    if (sm) {
-                        unsigned wbase = 0u;
-                        if (lane == 0) wbase = atomicAdd(&s_m, (unsigned)__popcll(sm));
-                        wbase = __shfl(wbase, 0);
-                        if (sel) ck[wbase + (unsigned)__popcll(sm & ((1ull << lane) - 1ull))] =
-                            ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                        if (b >= b0 && b <= b1)
+                            ck[atomicAdd(&s_cur[b], 1u)] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
                     }
                 }
             }
             __syncthreads();
             const int m = (int)s_m;
-            const unsigned long long hi_excl = ((unsigned long long)(b1 - b0 + 1) << shift);
-            const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
             // ---- order the chunk, then composite it
-            if (!(ablate & 1)) lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
+            if (!(ablate & 1)) {
+                if (!big) {
+                    lds_bucket_rank_sort<kChunk / kLazyThreads>(ck, m, b0, shift, s_hist, s_cur, perm);
+                } else {   // a crowded bucket (coplanar splats): radix passes cost the same whatever the distribution
+                    const unsigned long long hi_excl = ((unsigned long long)(b1 - b0 + 1) << shift);
+                    const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
+                    lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
+                }
+            }
             bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
                 all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, m,
