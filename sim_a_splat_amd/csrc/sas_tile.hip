@@ -145,31 +145,39 @@ DEV void lds_bucket_rank_sort(unsigned long long *buf, int m, int b0, int shift,
 {
     const int tid = threadIdx.x;
     unsigned long long key[NK];
-    int dst[NK];
+    int st[NK], len[NK], rank[NK];
+    int maxlen = 0;
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         const int i = u * kSortThreads + tid;
-        dst[u] = -1;
+        key[u] = 0ull;
+        st[u] = len[u] = rank[u] = 0;
         if (i < m) {
             key[u] = buf[i];
-            const unsigned hk = hi32(key[u]);
-            const int b = b0 + (int)(hk >> shift);
-            const int en = (int)cur[b], st = en - (int)hist[b];
-            int rank = 0;
-            for (int j = st; j < en; ++j) {
-                const unsigned long long kj = buf[j];
-                const unsigned hj = hi32(kj);
+            const int b = b0 + (int)(hi32(key[u]) >> shift);
+            len[u] = (int)hist[b];
+            st[u] = (int)cur[b] - len[u];
+        }
+        maxlen = max(maxlen, len[u]);
+    }
+    // the thread's keys walk their buckets side by side: their LDS reads are independent
+    for (int j = 0; j < maxlen; ++j) {
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            if (j < len[u]) {
+                const unsigned long long kj = buf[st[u] + j];
+                const unsigned hj = hi32(kj), hk = hi32(key[u]);
                 bool less = hj < hk;
-                if (hj == hk && j != i) less = perm[lo32(kj)] < perm[lo32(key[u])];   // identical depth words: rare
-                rank += less ? 1 : 0;
+                if (hj == hk && st[u] + j != u * kSortThreads + tid)
+                    less = perm[lo32(kj)] < perm[lo32(key[u])];   // identical depth words: rare
+                rank[u] += less ? 1 : 0;
             }
-            dst[u] = st + rank;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NK; ++u)
-        if (dst[u] >= 0) buf[dst[u]] = key[u];
+        if (len[u] > 0) buf[st[u] + rank[u]] = key[u];
     __syncthreads();
 }
 
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 #endif
 constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per round
 #ifndef SAS_TUNE_RANKMAX
-#define SAS_TUNE_RANKMAX 48
+#define SAS_TUNE_RANKMAX 32
 #endif
 constexpr int kRankMax = SAS_TUNE_RANKMAX;   // largest depth bucket a chunk is ordered by counting (else radix passes)
 constexpr int kLazyThreads = 256;
