@@ -66,6 +66,7 @@ def lib():
         _lib.sas_oracle_unproject.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_void_p] * 3
         _lib.sas_oracle_num_threads.restype = ctypes.c_int
+        _lib.sas_oracle_set_variant.argtypes = [ctypes.c_int]
         _lib.sas_oracle_set_num_threads.argtypes = [ctypes.c_int]
     return _lib
 
@@ -89,6 +90,25 @@ def expf(x: float) -> float:
 
 def logf(x: float) -> float:
     return float(lib().sas_oracle_logf(ctypes.c_float(x)))
+
+
+VARIANT_TEXTBOOK_SIGMA, VARIANT_SIGMA_GUARD, VARIANT_T_PRODUCT, VARIANT_LIBM_EXP = 1, 2, 4, 8
+
+
+class variant:
+    """``with oracle.variant(mask): ...`` -- switch compositing to textbook float32 forms for the deviation
+    study (sas_oracle.c blend_pixel_variant); mask 0 is the contract."""
+
+    def __init__(self, mask: int):
+        self.mask = int(mask)
+
+    def __enter__(self):
+        lib().sas_oracle_set_variant(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sas_oracle_set_variant(0)
+        return False
 
 
 def num_threads() -> int:

@@ -5,8 +5,11 @@
 (1) compute_cov.npz  -- inputs and outputs of the REFERENCE's own compute_cov, obtained by
     importing /root/reference/sim_a_splat/ellipsoids/covariance_utils.py by file path (a
     torch-only module).  Only data is stored, no reference source.
-(2) render_twin_*.npz -- tiny seeded scenes rendered by the float64 NumPy twin; they pin the
-    C oracle (tests/test_oracle.py) and, through it, the HIP kernels.
+(2) render_twin_*.npz -- seeded scenes rendered by the float64 NumPy twin (textbook formulas, libm exp);
+    they pin the C oracle (tests/test_oracle.py) AND the HIP kernels directly
+    (tests/test_gpu_parity.py::test_golden_twin_fixtures_through_the_c_abi): small cases, a dense
+    early-terminating slab (config 3's regime), a Door-B cov6 + RGB + group-pose case, a camera inside
+    the cloud.
 (3) scene_assets_xarm6_1.npz -- the small data files the reference ships for its real scene
     (robots-scene-v2 / xarm6-1): ICP similarity, mask-time joint configuration, dataparser
     transform and the seven per-link masks, bit-packed.  Data only; the masks' pickled .npy is
@@ -49,27 +52,66 @@ def gen_compute_cov():
     print("compute_cov.npz", covs.shape)
 
 
+def _dense_scene(n, seed):
+    """Config-3-like regime on a small image: a thick slab of small, fairly opaque Gaussians in front of
+    the camera, so that every tile list runs to thousands of entries, is composited through several
+    512-entry chunks and almost every pixel ends on the T <= 1e-4 stop after hundreds of splats."""
+    from sim_a_splat_amd.synthetic import SyntheticScene
+    rng = np.random.default_rng(seed)
+    means = np.stack([rng.uniform(-1.3, 1.3, n), rng.uniform(-0.9, 0.9, n), rng.uniform(-0.8, 0.8, n)], 1)
+    log_s = np.clip(rng.normal(np.log(0.06), 0.5, (n, 3)), np.log(2e-3), np.log(0.2))
+    logit = rng.normal(-1.2, 1.2, n)
+    dc = rng.normal(0.0, 1.0, (n, 1, 3))
+    rest = rng.normal(0.0, 0.15, (n, 3, 3))
+    return SyntheticScene(means=means.astype(np.float32), quats=rng.normal(size=(n, 4)).astype(np.float32),
+                          scales=np.exp(log_s).astype(np.float32),
+                          opacities=(1.0 / (1.0 + np.exp(-logit))).astype(np.float32),
+                          sh=np.concatenate([dc, rest], 1).astype(np.float32), sh_degree=1)
+
+
 def gen_twin_renders():
-    from oracle import np_twin
-    from sim_a_splat_amd.synthetic import make_scene, ring_camera, random_group_poses, NERFSTUDIO_EVAL_BACKGROUND
+    from oracle import np_twin, ref_math
+    from sim_a_splat_amd.synthetic import (make_scene, ring_camera, random_group_poses, look_at_viewmat, intrinsics, Camera,
+                                           NERFSTUDIO_EVAL_BACKGROUND)
     cases = {
         "one": dict(n=1, seed=11, w=32, h=32, f=40.0, ls=np.log(0.15)),
         "two": dict(n=2, seed=12, w=48, h=32, f=40.0, ls=np.log(0.2)),
         "n64": dict(n=64, seed=13, w=64, h=64, f=60.0, ls=np.log(0.08)),
         "n2k": dict(n=2000, seed=14, w=128, h=96, f=120.0, ls=np.log(0.03)),
         "n2k_groups": dict(n=2000, seed=15, w=100, h=70, f=90.0, ls=np.log(0.03), groups=5),
+        # the regime config 3 lives in: lists of thousands, several lazy chunks per tile, early termination
+        "dense": dict(dense=20000, seed=16, w=96, h=64, f=75.0),
+        # Door B: 3x3 covariances (reference compute_cov semantics) + final RGB + group poses
+        "doorb": dict(n=3000, seed=17, w=112, h=80, f=100.0, ls=np.log(0.04), groups=4, door_b=True),
+        # camera inside the cloud: near-plane cull, clamped Jacobian (0.3 tan_fov limits), huge footprints
+        "inside": dict(n=1500, seed=18, w=96, h=80, f=70.0, ls=np.log(0.05), inside=True),
     }
     for name, c in cases.items():
-        sc = make_scene(c["n"], seed=c["seed"], log_scale_mean=float(c["ls"]), n_groups=c.get("groups", 0))
-        cam = ring_camera(c["w"], c["h"], c["f"], yaw_deg=20.0, elev=0.3)
+        if "dense" in c:
+            sc = _dense_scene(c["dense"], c["seed"])
+        else:
+            sc = make_scene(c["n"], seed=c["seed"], log_scale_mean=float(c["ls"]), n_groups=c.get("groups", 0))
+        if c.get("inside"):
+            cam = Camera(look_at_viewmat((0.15, -0.1, 0.2), target=(0.4, 0.1, -1.0)), intrinsics(c["f"], c["f"], c["w"] / 2.0, c["h"] / 2.0),
+                         c["w"], c["h"])
+        else:
+            cam = ring_camera(c["w"], c["h"], c["f"], yaw_deg=20.0, elev=0.3)
         gRt = random_group_poses(c["groups"], seed=c["seed"]) if c.get("groups") else None
-        out = np_twin.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height,
-                             quats=sc.quats, scales=sc.scales, sh_degree=3, group_id=sc.group_id, group_Rt=gRt,
-                             background=NERFSTUDIO_EVAL_BACKGROUND, depth_mode=0)
+        kw = dict(quats=sc.quats, scales=sc.scales, sh_degree=sc.sh_degree)
+        colors, cov6 = sc.sh, np.zeros((0, 6), np.float32)
+        if c.get("door_b"):
+            cov = ref_math.compute_cov(sc.quats, sc.scales).astype(np.float32)          # a5: what the loader hands to Door B
+            cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+            colors = ref_math.sh2rgb(sc.sh[:, 0, :]).astype(np.float32)                  # a3: SH2RGB(features_dc), no clamp
+            kw = dict(cov6=cov6, sh_degree=-1)
+        out = np_twin.render(sc.means, sc.opacities, colors, cam.viewmat, cam.K, cam.width, cam.height,
+                             group_id=sc.group_id, group_Rt=gRt, background=NERFSTUDIO_EVAL_BACKGROUND, depth_mode=0, **kw)
         P = out["proj"]
         np.savez_compressed(
             GOLD / f"render_twin_{name}.npz",
-            means=sc.means, quats=sc.quats, scales=sc.scales, opacities=sc.opacities, sh=sc.sh,
+            means=sc.means, quats=sc.quats if not c.get("door_b") else np.zeros((0, 4), np.float32),
+            scales=sc.scales if not c.get("door_b") else np.zeros((0, 3), np.float32), cov6=cov6,
+            opacities=sc.opacities, colors=colors, sh_degree=np.int32(kw["sh_degree"]),
             group_id=sc.group_id if sc.group_id is not None else np.zeros(0, np.uint8),
             group_Rt=gRt if gRt is not None else np.zeros((0, 12), np.float32),
             viewmat=cam.viewmat, K=cam.K, wh=np.array([cam.width, cam.height]),
@@ -77,8 +119,9 @@ def gen_twin_renders():
             rgb=out["rgb"].astype(np.float32), alpha=out["alpha"].astype(np.float32),
             depth=out["depth"].astype(np.float32), radii=P["radii"], valid=P["valid"],
             means2d=P["means2d"].astype(np.float32), conics=P["conics"].astype(np.float32),
-            colors=P["colors"].astype(np.float32), n_isect=np.array(out["n_isect"]))
-        print(name, out["n_visible"], out["n_isect"])
+            rgb_gauss=P["colors"].astype(np.float32), n_isect=np.array(out["n_isect"]))
+        term = int(((1.0 - out["alpha"]) < 1e-3).sum())   # a stopped pixel keeps the T it had BEFORE the stopping splat
+        print(f"{name}: visible {out['n_visible']}, intersections {out['n_isect']}, saturated pixels (T < 1e-3) {term} of {cam.width * cam.height}")
 
 
 ASSETS = Path("/root/reference/assets/robots-scene-v2")

@@ -427,6 +427,50 @@ static inline void blend_pixel(const proj_t *P, const int32_t *ids, const tcoef_
     *out_T = T;
 }
 
+/* ---- deviation study (tests/test_oracle.py, tools/deviation_table.py) ---------------------------------
+ * The contract departs from gsplat's WRITTEN arithmetic in four places, each chosen for the GPU loop.
+ * A variant mask switches any of them back to the textbook float32 form, so that the effect of each on an
+ * image can be measured against the float64 twin (oracle/np_twin.py, which keeps all four textbook forms):
+ *   1  sigma = 0.5 (A dx^2 + C dy^2) + B dx dy on (dx, dy) = (mx - px, my - py) instead of the tile polynomial
+ *   2  gsplat's `sigma < 0 -> skip` guard restored
+ *   4  T' = T (1 - alpha) instead of T - alpha T
+ *   8  libm expf instead of the degree-5 polynomial
+ * Mask 0 is the contract and the only thing the parity tests and the CPU baseline ever run. */
+static int g_variant = 0;
+void sas_oracle_set_variant(int mask) { g_variant = mask; }
+
+static inline void blend_pixel_variant(int variant, const proj_t *P, const int32_t *ids, const tcoef_t *tc, int64_t n,
+                                       float x, float y, float px, float py, float out_acc[4], float *out_T)
+{
+    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, ad = 0.0f;
+    const float xx = x * x, yy = y * y, xy = x * y;
+    for (int64_t k = 0; k < n; ++k) {
+        const proj_t *g = &P[ids[k]];
+        const tcoef_t *t = &tc[k];
+        float sigma;
+        if (variant & 1) {
+            float dx = g->mx - px, dy = g->my - py;
+            sigma = 0.5f * (g->ca * dx * dx + g->cc * dy * dy) + g->cb * dx * dy;
+        } else {
+            sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
+        }
+        if ((variant & 2) && sigma < 0.0f) continue;
+        float e = (variant & 8) ? expf(-sigma) : sas_oracle_expf(-sigma);
+        float alpha = fminf(OC_MAX_ALPHA, g->opac * e);
+        if (alpha < OC_ALPHA_THRESHOLD) continue;
+        float vis = alpha * T;
+        float next_T = (variant & 4) ? T * (1.0f - alpha) : T - vis;
+        if (next_T <= OC_T_STOP) break;
+        ar = fmaf(g->rgb[0], vis, ar);
+        ag = fmaf(g->rgb[1], vis, ag);
+        ab = fmaf(g->rgb[2], vis, ab);
+        ad = fmaf(g->depth, vis, ad);
+        T = next_T;
+    }
+    out_acc[0] = ar; out_acc[1] = ag; out_acc[2] = ab; out_acc[3] = ad;
+    *out_T = T;
+}
+
 /*
  * Full frame.  depth_mode: 0 = expected depth ED = acc_d / max(alpha,1e-10) (gsplat "RGB+ED");
  *              1 = nerfstudio fill, where(alpha > 0, ED, max(ED)).
@@ -505,7 +549,9 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
                 int j = tx * OC_TILE + xx;
                 if (j >= W) break;
                 float acc[4], T;
-                blend_pixel(P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f, acc, &T);
+                if (g_variant == 0) blend_pixel(P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f, acc, &T);
+                else blend_pixel_variant(g_variant, P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f,
+                                         (float)j + 0.5f, (float)i + 0.5f, acc, &T);
                 float a = 1.0f - T;
                 int64_t pix = (int64_t)i * W + j;
                 float ED = acc[3] / fmaxf(a, 1e-10f);

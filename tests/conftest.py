@@ -28,3 +28,25 @@ def rasterizer():
     r = Rasterizer(0)
     yield r
     r.close()
+
+
+TWIN_CASES = ["one", "two", "n64", "n2k", "n2k_groups", "dense", "doorb", "inside"]
+
+
+def load_twin_fixture(name):
+    """tests/golden/render_twin_<name>.npz (oracle/make_golden.py): inputs + float64-twin frames."""
+    import numpy as np
+    return np.load(GOLDEN / f"render_twin_{name}.npz")
+
+
+def twin_scene_kwargs(g):
+    """Scene arguments of a twin fixture in the form both oracle.render and Rasterizer.upload take:
+    (means, opacities, colors, kwargs) with quats+scales or cov6, sh_degree (< 0: final RGB), groups."""
+    kw = dict(sh_degree=int(g["sh_degree"]))
+    if g["cov6"].size:
+        kw["cov6"] = g["cov6"]
+    else:
+        kw.update(quats=g["quats"], scales=g["scales"])
+    if g["group_id"].size:
+        kw["group_id"] = g["group_id"]
+    return g["means"], g["opacities"], g["colors"], kw

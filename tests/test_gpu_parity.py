@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import TWIN_CASES, load_twin_fixture, twin_scene_kwargs
 from sim_a_splat_amd.synthetic import (NERFSTUDIO_EVAL_BACKGROUND, config_scene_and_cameras, make_scene,
                                        random_group_poses, ring_camera)
 
@@ -296,6 +297,39 @@ def test_config5_view_5m_gaussians(rasterizer):
     _compare(rasterizer, sc, cams[1])
     st = rasterizer.stats()
     assert st["n_isect"] > 10_000_000 and st["max_tile_len"] > 16384
+
+
+@pytest.mark.parametrize("name", TWIN_CASES)
+def test_golden_twin_fixtures_through_the_c_abi(rasterizer, name):
+    """The committed float64-twin fixtures (tests/golden/render_twin_*.npz: textbook formulas, libm exp, an
+    independent implementation) rendered by the HIP path through the C ABI and compared with the stored
+    frames DIRECTLY, at the north_star tolerance: rgb / alpha <= 1e-4 max abs, depth <= 1e-3 relative.
+    Covers lists of thousands with several lazy chunks and early termination ("dense"), Door B's cov6 +
+    final RGB + group poses ("doorb") and a camera inside the cloud ("inside").  The HIP frame must also
+    equal the C oracle bit for bit, so the two pins cannot drift apart."""
+    g = load_twin_fixture(name)
+    means, op, colors, kw = twin_scene_kwargs(g)
+    W, H = [int(v) for v in g["wh"]]
+    up = dict(kw)
+    cov6 = up.pop("cov6", None)
+    gid = up.pop("group_id", None)
+    rasterizer.upload(means, op, colors, quats=up.get("quats"), scales=up.get("scales"), covariances=cov6,
+                      sh_degree=up["sh_degree"], group_id=gid, n_groups=int(g["group_Rt"].shape[0]) if gid is not None else 0)
+    if gid is not None:
+        rasterizer.set_group_poses(g["group_Rt"])
+    bg = tuple(float(v) for v in g["background"])
+    out = rasterizer.render(g["viewmat"], g["K"], W, H, bg, want=("rgb", "alpha", "depth"))
+    rgb, alpha, depth = (out[k].cpu().numpy() for k in ("rgb", "alpha", "depth"))
+    assert np.abs(rgb - g["rgb"]).max() <= TOL
+    assert np.abs(alpha - g["alpha"]).max() <= TOL
+    solid = g["alpha"] > 0.5
+    if solid.any():
+        assert (np.abs(depth - g["depth"])[solid] / g["depth"][solid]).max() <= 1e-3
+    st = rasterizer.stats()
+    assert st["n_isect"] == int(g["n_isect"]) and st["n_visible"] == int(g["valid"].sum())
+    ref = oracle.render(means, op, colors, g["viewmat"], g["K"], W, H, group_Rt=g["group_Rt"] if gid is not None else None,
+                        background=bg, **kw)
+    assert np.array_equal(rgb, ref["rgb"]) and np.array_equal(alpha, ref["alpha"]) and np.array_equal(depth, ref["depth"])
 
 
 def test_async_frames_and_stream_ordering(rasterizer):

@@ -4,21 +4,18 @@ import pytest
 
 import oracle
 from oracle import np_twin, ref_math
-
-CASES = ["one", "two", "n64", "n2k", "n2k_groups"]
+from conftest import TWIN_CASES as CASES, load_twin_fixture, twin_scene_kwargs
 
 
 def _load(golden_dir, name):
-    return np.load(golden_dir / f"render_twin_{name}.npz")
+    return load_twin_fixture(name)
 
 
 def _oracle_from_fixture(g, **kw):
-    gid = g["group_id"] if g["group_id"].size else None
+    means, op, colors, skw = twin_scene_kwargs(g)
     gRt = g["group_Rt"] if g["group_Rt"].size else None
     W, H = [int(v) for v in g["wh"]]
-    return oracle.render(g["means"], g["opacities"], g["sh"], g["viewmat"], g["K"], W, H, quats=g["quats"],
-                         scales=g["scales"], sh_degree=3, group_id=gid, group_Rt=gRt,
-                         background=g["background"], **kw)
+    return oracle.render(means, op, colors, g["viewmat"], g["K"], W, H, group_Rt=gRt, background=g["background"], **skw, **kw)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -31,7 +28,7 @@ def test_oracle_matches_float64_twin_golden(golden_dir, name):
     np.testing.assert_allclose(o["means2d"][valid], g["means2d"][valid], atol=2e-4, rtol=1e-6)
     scale = np.abs(g["conics"][valid]).max(axis=1, keepdims=True)
     assert np.max(np.abs(o["conics"][valid] - g["conics"][valid]) / scale) < 2e-5
-    np.testing.assert_allclose(o["colors"][valid], g["colors"][valid], atol=2e-6)
+    np.testing.assert_allclose(o["colors"][valid], g["rgb_gauss"][valid], atol=2e-6)
     # float32 vs float64: no pixel may differ beyond float32 accumulation error unless a threshold decision flipped
     for k, tol in (("rgb", 5e-5), ("alpha", 5e-5)):
         d = np.abs(o[k] - g[k])
@@ -76,10 +73,10 @@ def test_single_gaussian_analytic_footprint():
 def test_permutation_invariance_without_depth_ties():
     g = np.load(pytest.importorskip("pathlib").Path(__file__).parent / "golden" / "render_twin_n64.npz")
     W, H = [int(v) for v in g["wh"]]
-    base = oracle.render(g["means"], g["opacities"], g["sh"], g["viewmat"], g["K"], W, H, quats=g["quats"],
+    base = oracle.render(g["means"], g["opacities"], g["colors"], g["viewmat"], g["K"], W, H, quats=g["quats"],
                          scales=g["scales"], background=g["background"])
     perm = np.random.default_rng(0).permutation(g["means"].shape[0])
-    p = oracle.render(g["means"][perm], g["opacities"][perm], g["sh"][perm], g["viewmat"], g["K"], W, H,
+    p = oracle.render(g["means"][perm], g["opacities"][perm], g["colors"][perm], g["viewmat"], g["K"], W, H,
                       quats=g["quats"][perm], scales=g["scales"][perm], background=g["background"])
     assert np.array_equal(base["rgb"], p["rgb"]) and np.array_equal(base["alpha"], p["alpha"])
 
@@ -164,3 +161,21 @@ def test_oracle_under_address_and_ub_sanitizers():
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr
     assert res.stdout.count("intersections") == 5
+
+
+def test_contract_deviations_from_the_textbook_formulas_stay_far_below_the_parity_tolerance():
+    """The contract departs from gsplat's written arithmetic in four places.  On every
+    committed twin fixture -- including the dense early-terminating one, the Door-B one and the camera
+    inside the cloud -- each of them alone moves no pixel by more than 5e-5 against the all-textbook
+    float32 evaluation, the sigma < 0 guard never fires, and the contract as a whole stays within 5e-5 of
+    the float64 twin (north_star tolerance: 1e-4).  tools/deviation_table.py prints the numbers."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("deviation_table", Path(__file__).resolve().parent.parent / "tools" / "deviation_table.py")
+    dt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dt)
+    for name in CASES:
+        row = dt.measure(name)
+        assert row["no sigma<0 guard"] == 0.0, row
+        for label in ("polynomial sigma", "T - alpha T", "polynomial exp", "contract vs f64 twin", "textbook f32 vs f64 twin"):
+            assert row[label] <= 5e-5, (label, row)
