@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: rendered frames/s at 1M Gaussians, 1920x1080 (BASELINE.json config 3).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path (project + SH, bin, per-tile sort, blend) over one batch of two
-independent 1080p views per GPU (one sas_render_batch call; the pair shares one projection pass) of
-one synthetic 1M-Gaussian scene resident in HBM, float32 RGB + uint8 RGB out per view.  With N > 1
-every rank renders its own views of the replicated scene (weak scaling) and the finished
-uint8 frames are gathered to rank 0 over RCCL, one step behind the renderer.  Rank 0 prints ONE JSON
-line; value = frames/s over all ranks.  The oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
+A step is one pass of the hot path (project + SH, bin, per-tile depth order, composite) over one batch
+of independent views per GPU of a synthetic scene resident in HBM:
+
+  config 3 (default, the metric's config)  1M Gaussians, SH degree 3, 1920x1080, two views per GPU per
+            step (one sas_render_batch call; the pair shares one projection pass), float32 RGB + uint8 RGB
+            out per view.  Weak scaling: every rank renders its own views of the replicated scene.
+  config 4  292,247-Gaussian grouped scene (7 link groups, poses updated every step), 8 ring poses at
+            640x480, uint8 frames, the 8 views sharded over the ranks (strong scaling, north_star
+            "one per GPU on 8 GPUs").
+  config 5  5M Gaussians, four 1920x1080 views sharded over (up to 4) ranks (strong scaling).
+
+With N > 1 the finished uint8 frames are gathered to rank 0 over RCCL as soon as the renderer reports
+them complete (sim_a_splat_amd.distributed.StepPipeline).  Rank 0 prints ONE JSON line; value = frames/s
+over all ranks.  The oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
 """
 from __future__ import annotations
 
@@ -30,38 +38,54 @@ sys.path.insert(0, str(ROOT))
 
 from sim_a_splat_amd import distributed as sdist  # noqa: E402
 from sim_a_splat_amd.rasterizer import Rasterizer  # noqa: E402
-from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, make_scene, ring_camera  # noqa: E402
+from sim_a_splat_amd.synthetic import (NERFSTUDIO_EVAL_BACKGROUND as BG, config_scene_and_cameras, make_scene,  # noqa: E402
+                                       random_group_poses, ring_camera)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Vector-instruction issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 3.0 cycles per wave-instruction, the rate a
+# SIMD sustains on independent v_fma_f32 with 4-8 waves resident (tools/microbench/pk_f32_rate.hip, measured
+# 3.0-3.35; scalar instructions go through one unit per CU and cost the same issue time)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 3.0
 
 
-def algorithmic_bytes(n, n_vis, m, w, h, out_bytes_per_pixel=15):
-    """N*236 + N_vis*44 + M*60 + W*H*out."""
-    return n * 236 + n_vis * 44 + m * 60 + w * h * out_bytes_per_pixel
+def scene_pass_bytes(n):
+    """the N*236 B of Gaussian attributes one projection pass reads."""
+    return n * 236
 
 
-def tile_kernel_bytes(m, w, h, out_bytes_per_pixel=15):
+def view_bytes(n_vis, m, w, h, out_bytes_per_pixel):
+    """SURVEY.md 8d, the per-view terms: N_vis*44 + M*60 + W*H*out."""
+    return n_vis * 44 + m * 60 + w * h * out_bytes_per_pixel
+
+
+def tile_kernel_bytes(m, w, h, out_bytes_per_pixel):
     """Dominant kernel (k_tile_lazy = per-tile ordering + compositing), SURVEY.md 8d terms:
     8 B key read per intersection + 44 B gather per intersection (id 4 + record 40) + the frame."""
     return m * (8 + 44) + w * h * out_bytes_per_pixel
 
 
+def committed(name):
+    p = ROOT / "profiles" / name
+    try:
+        return json.loads(p.read_text())
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE is
     doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no summary is committed."""
-    p = ROOT / "profiles" / "hbm_traffic.json"
-    if not p.exists():
-        return None
+    d = committed("hbm_traffic.json")
     try:
-        return json.loads(p.read_text())["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (KeyError, ValueError):
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, TypeError):
         return None
 
 
 def cpu_baseline(scene, cam, budget_s=20.0):
     import oracle
     threads = oracle.num_threads()
-    kw = dict(quats=scene.quats, scales=scene.scales, sh_degree=3, background=NERFSTUDIO_EVAL_BACKGROUND)
+    kw = dict(quats=scene.quats, scales=scene.scales, sh_degree=3, background=BG)
     t0 = time.perf_counter()
     oracle.render(scene.means, scene.opacities, scene.sh, cam.viewmat, cam.K, cam.width, cam.height, **kw)
     first = time.perf_counter() - t0
@@ -76,16 +100,40 @@ def cpu_baseline(scene, cam, budget_s=20.0):
                       f"OpenMP on {threads} threads of {os.cpu_count()} host CPUs"}
 
 
+def workload(cfg, rank, world, views_per_step, n_gaussians):
+    """(scene, cameras of THIS rank, want, per-step group poses or None, description, scaling, all-rank views per step)."""
+    if cfg == 3:
+        scene = make_scene(n_gaussians, seed=3, log_scale_mean=float(np.log(0.006)))
+        cams = [ring_camera(1920, 1080, 1000.0, yaw_deg=45.0 * rank + 180.0 * v) for v in range(views_per_step)]
+        desc = (f"BASELINE config 3: {n_gaussians / 1e6:g}M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, fx=fy=1000, "
+                f"{views_per_step} independent view(s) per GPU per step"
+                + (" (a view pair shares one projection pass)" if views_per_step == 2 else "") + ", float32 RGB + uint8 RGB out per view")
+        return scene, cams, ("rgb", "rgb8"), None, desc, "weak", world * views_per_step
+    scene, all_cams = config_scene_and_cameras(cfg)
+    mine = sdist.shard_views(len(all_cams), rank, world)
+    cams = [all_cams[v] for v in mine]
+    if cfg == 4:
+        poses = [random_group_poses(7, seed=1000 + s) for s in range(16)]   # a rollout's link poses, cycled
+        desc = ("BASELINE config 4: 292,247-Gaussian stand-in of the pushT scene (seed 2, SH degree 3, 7 link groups, poses updated every "
+                f"step), 8 ring poses at 640x480 sharded over {world} GPU(s), uint8 RGB out (Door B)")
+        return scene, cams, ("rgb8",), poses, desc, "strong", len(all_cams)
+    desc = (f"BASELINE config 5: 5M synthetic Gaussians (seed 5, SH degree 3), four 1920x1080 views (yaw 0/90/180/270) sharded over "
+            f"{min(world, 4)} GPU(s), float32 RGB + uint8 RGB out per view")
+    return scene, cams, ("rgb", "rgb8"), None, desc, "strong", len(all_cams)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json config (3 = the metric's)")
+    ap.add_argument("--gaussians", type=int, default=1_000_000, help="config 3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-view / Door-A / per-stage measurements after the timed region")
     ap.add_argument("--time-every", type=int, default=4, help="steps between tile-kernel timing samples")
     ap.add_argument("--views-per-step", type=int, default=2, choices=(1, 2),
-                    help="independent views each GPU renders per step; 2 = a view pair (one projection pass for both)")
+                    help="config 3: independent views each GPU renders per step; 2 = a view pair (one projection pass for both)")
     a = ap.parse_args()
 
     rank, world, local_rank = sdist.init_from_env()
@@ -95,53 +143,52 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    W, H = 1920, 1080
-    scene = make_scene(a.gaussians, seed=3, log_scale_mean=float(np.log(0.006)))
-    # independent views: GPU g renders the ring cameras at yaw 45 g (and 45 g + 180 for the second view of a pair)
-    VPS = a.views_per_step
-    cams = [ring_camera(W, H, 1000.0, yaw_deg=45.0 * rank + 180.0 * v) for v in range(VPS)]
-    cam = cams[0]
-    Vs, Ks = np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams])
+    scene, cams, want, step_poses, desc, scaling, views_all = workload(a.config, rank, world, a.views_per_step, a.gaussians)
+    V = len(cams)                                  # views this rank renders per step (0 for a rank beyond the view count)
+    cam = cams[0] if cams else ring_camera(1920, 1080, 1000.0)
+    W, H = (cam.width, cam.height)
     r = Rasterizer(dev)
-    r.upload(scene.means, scene.opacities, scene.sh, quats=scene.quats, scales=scene.scales, sh_degree=3)
-    # every rank writes the float32 frames (the metric's output) and their uint8 twins; the gather moves
-    # the uint8 frames, the format Gym observations are exchanged in (splat_env_wrapper.py:135-137):
-    # 6.2 MB instead of 24.9 MB per frame keeps the xGMI transfer shorter than a frame
-    bufs = [{"rgb": torch.empty((VPS, H, W, 3), dtype=torch.float32, device=dev),
-             "rgb8": torch.empty((VPS, H, W, 3), dtype=torch.uint8, device=dev)} for _ in range(3)]
-    gather = sdist.FrameGather(world, rank)
+    r.upload(scene.means, scene.opacities, scene.sh, quats=scene.quats, scales=scene.scales, sh_degree=3,
+             group_id=scene.group_id if step_poses else None, n_groups=7 if step_poses else 0)
+    Vs = np.stack([c.viewmat for c in cams]) if cams else np.zeros((0, 4, 4), np.float32)
+    Ks = np.stack([c.K for c in cams]) if cams else np.zeros((0, 3, 3), np.float32)
+    # Every rank writes the outputs the config names; the gather moves the uint8 frames, the format Gym
+    # observations are exchanged in (splat_env_wrapper.py:135-137): 6.2 MB instead of 24.9 MB per 1080p frame
+    # keeps the xGMI transfer shorter than a frame.  Four buffers: frames complete up to two steps behind
+    # their submission and one gather may still be reading (distributed.StepPipeline).
+    VB = max(V, 1)
+    shapes = {"rgb": ((VB, H, W, 3), torch.float32), "rgb8": ((VB, H, W, 3), torch.uint8)}
+    bufs = [{k: torch.zeros(shapes[k][0], dtype=shapes[k][1], device=dev) for k in want} for _ in range(4)]
+    timing_on = [False]
+    idle_steps = [0]   # a rank beyond the view count (config 5 on 8 GPUs) renders nothing: its steps are complete at once
 
-    def step(i, timing):
-        out = bufs[i % 3]
-        # one C-ABI call per step: the step's views go through the frame slots back to back, a pair of
-        # views shares one pass over the scene (sas_render_batch)
-        r.render_batch(Vs, Ks, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"), out=out, block=False,
-                       time_tiles=timing)
-        # After the call returns, the current stream is ordered behind every view of step i-1 (C ABI
-        # contract): gather those, so the xGMI transfer of step i-1 overlaps the rendering of step i.
-        if world > 1 and i > 0:
-            gather.start(bufs[(i - 1) % 3]["rgb8"])
+    def submit(i, out):
+        if step_poses is not None:
+            r.set_group_poses(step_poses[i % len(step_poses)])   # the Gym step's new link poses (completes the frames in flight)
+        if V:
+            r.render_batch(Vs, Ks, W, H, BG, want=want, out={k: v[:V] for k, v in out.items()}, block=False, time_tiles=timing_on[0])
+        else:
+            idle_steps[0] += 1
 
-    def sync(last_i):
-        r.wait()                       # orders the current stream behind every frame
-        if world > 1:
-            if last_i >= 0:
-                gather.start(bufs[last_i % 3]["rgb8"])
-            gather.finish()
+    pipe = sdist.StepPipeline(world, rank, bufs, submit, lambda: (r.frames_completed()[1] // V) if V else idle_steps[0], r.wait,
+                              payload=lambda b: b["rgb8"])
+
+    def run(steps, time_every):
+        pipe.begin()
+        for i in range(steps):
+            # SAS_TIME_TILES on every time_every-th step: HIP events around the dominant kernel of that
+            # step's frames (on the kernel's own stream); the frames keep pipelining
+            timing_on[0] = time_every > 0 and i % time_every == 0
+            pipe.step()
+        pipe.drain()               # completes every frame, gathers what is left
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    for i in range(a.warmup):
-        step(i, True)
-    sync(a.warmup - 1)
+    run(a.warmup, 1)
     r.stage_time_means(reset=True)
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        # SAS_TIME_TILES on every TIME_EVERY-th step: HIP events around the dominant kernel of that
-        # step's frames (on the kernel's own stream), the frames keep pipelining
-        step(i, i % a.time_every == 0)
-    sync(a.steps - 1)
+    run(a.steps, a.time_every)
     elapsed = time.perf_counter() - t0
     means, timed_frames = r.stage_time_means(reset=True)
     tile_ms = means["blend"]
@@ -149,50 +196,93 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # intersections / visible Gaussians of each view of the step (the mean enters the byte counts)
-    per_view = []
-    for c_ in cams:
-        r.render(c_.viewmat, c_.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out={"rgb": bufs[0]["rgb"][0]})
-        per_view.append(r.stats())
-    st = {k: int(round(np.mean([pv[k] for pv in per_view]))) for k in ("n_visible", "n_isect")}
 
-    # per-stage breakdown of an isolated frame (nothing else on the GPU): 10 frames with events at
-    # every stage boundary, after the timed region
-    stage = {}
-    for i in range(10):
-        r.render(cam.viewmat, cam.K, W, H, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb", "rgb8"),
-                 out={k: v[0] for k, v in bufs[0].items()}, timing=True)
-        for k, v in r.stage_times().items():
-            stage.setdefault(k, []).append(v)
-    blend_s = tile_ms * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
-
+    line = None
     if rank == 0:
+        # intersections / visible Gaussians of each view of the step (their mean enters the byte counts)
+        if step_poses is not None:
+            r.set_group_poses(step_poses[0])
+        per_view = []
+        for c_ in cams:
+            r.render(c_.viewmat, c_.K, W, H, BG, want=("rgb8",), out={"rgb8": bufs[0]["rgb8"][0]})
+            per_view.append(r.stats())
+        st = {k: int(round(np.mean([pv[k] for pv in per_view]))) for k in ("n_visible", "n_isect")}
+        out_bpp = (12 if "rgb" in want else 0) + 3
         ms_per_step = elapsed / a.steps * 1e3
-        fps = world * VPS * a.steps / elapsed
-        achieved = tile_kernel_bytes(st["n_isect"], W, H) / blend_s / 1e9
-        frame_bytes = algorithmic_bytes(scene.n, st["n_visible"], st["n_isect"], W, H)
+        fps = views_all * a.steps / elapsed
+        blend_s = max(tile_ms, 1e-9) * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
+        achieved = tile_kernel_bytes(st["n_isect"], W, H, out_bpp) / blend_s / 1e9
+        # bytes one step of THIS rank moves: one pass over the scene per view pair (config 3 with two views per
+        # step: ONE pass for both), plus the per-view terms
+        pair = a.config == 3 and a.views_per_step == 2 or (a.config != 3 and scene.n >= 500_000 and V >= 2)
+        passes = (V + 1) // 2 if pair else V
+        step_bytes = passes * scene_pass_bytes(scene.n) + V * view_bytes(st["n_visible"], st["n_isect"], W, H, out_bpp)
+        step_gbps = step_bytes / (elapsed / a.steps) / 1e9
+        metric = "rendered frames/sec at 1M Gaussians 1920x1080" if a.config == 3 else \
+            f"rendered frames/sec, BASELINE config {a.config} ({scene.n} Gaussians, {W}x{H})"
         line = {
-            "metric": "rendered frames/sec at 1M Gaussians 1920x1080",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": metric, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: 1M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, "
-                                   f"fx=fy=1000, {VPS} independent view(s) per GPU per step"
-                                   + (" (a view pair shares one projection pass)" if VPS == 2 else "")
-                                   + ", float32 RGB + uint8 RGB out per view",
-                       "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
-                       "views_per_step": world * VPS, "parallelism": f"views{world}x{VPS}",
-                       "gather": "uint8 frames to rank 0 (RCCL), one step behind the renderer" if world > 1 else "none"},
+            "config": {"workload": desc, "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
+                       "views_per_step": views_all, "parallelism": f"views{world}x{V}",
+                       "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy"),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy") if a.config == 3 else None,
                          "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames,
-                         "kernel_ms_isolated_frame": float(np.mean(stage["blend"])),
-                         "frame_algorithmic_GBps": frame_bytes / (elapsed / a.steps / VPS) / 1e9,
-                         "frame_frac": frame_bytes / (elapsed / a.steps / VPS) / 1e9 / HBM_PEAK_GBPS,
-                         "isolated_frame_stage_ms": {k: float(np.mean(v)) for k, v in stage.items()}},
+                         "step_algorithmic_bytes": step_bytes, "frame_algorithmic_GBps": step_gbps,
+                         "frame_frac": step_gbps / HBM_PEAK_GBPS},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene, cam)
+        # The tile kernel moves 211 MB in ~135 us: HBM is not what bounds it.  Its roof is instruction issue;
+        # instruction counts per launch come from the committed rocprofv3 --pmc summary of this command.
+        insts = committed("tile_insts.json") if a.config == 3 else None
+        if insts:
+            valu, salu = insts["valu_insts_per_launch"], insts["salu_insts_per_launch"]
+            line["roofline_issue"] = {
+                "bound": "vector-instruction issue", "kernel": "k_tile_lazy", "unit": "G wave-instructions/s",
+                "achieved": valu / blend_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "frac": valu / blend_s / VALU_ISSUE_PEAK,
+                "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+                "frac_with_scalar": (valu + salu) / blend_s / VALU_ISSUE_PEAK,
+                "useful_frac": insts.get("composited_pixel_splats", 0) * insts.get("valu_per_composited_pixel_splat", 24) / 64 / blend_s / VALU_ISSUE_PEAK,
+                "source": "profiles/tile_insts.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, -DSAS_TUNE_STATS counters)"}
+
+    if rank == 0 and world == 1 and a.config == 3 and not a.no_extras:
+        # ---- what the reference's own callers do (not part of `value`) --------------------------------------------
+        c0 = cams[0]
+        K2 = max(50, a.steps)
+        # (1) one view per call, asynchronous
+        for rep in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(K2):
+                r.render(c0.viewmat, c0.K, W, H, BG, want=("rgb", "rgb8"), out={k: v[0] for k, v in bufs[i % 4].items()}, block=False)
+            r.wait()
+            torch.cuda.synchronize(dev)
+            dt1 = time.perf_counter() - t0
+        line["single_view_async"] = {"value": K2 / dt1, "unit": "frames/s", "what": "one view per sas_render call, SAS_ASYNC, rgb + rgb8"}
+        # (2) Door A exactly as GaussianSplat.render times it (nerfstudio_utils.py:163-175): blocking, one view,
+        #     rgb + accumulation + depth with the max-depth fill
+        o3 = {"rgb": bufs[0]["rgb"][0], "alpha": torch.empty((H, W, 1), device=dev), "depth": torch.empty((H, W, 1), device=dev)}
+        for rep in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(K2):
+                r.render(c0.viewmat, c0.K, W, H, BG, want=("rgb", "alpha", "depth"), depth_fill_max=True, out=o3)
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t0
+        line["door_a_sync"] = {"value": K2 / dt2, "unit": "frames/s", "ms_per_frame": dt2 / K2 * 1e3,
+                               "what": "blocking single view, rgb + alpha + depth, SAS_DEPTH_FILL_MAX (the reference's call pattern)"}
+        # (3) per-stage breakdown of an isolated frame (nothing else on the GPU)
+        stage = {}
+        for i in range(10):
+            r.render(c0.viewmat, c0.K, W, H, BG, want=("rgb", "rgb8"), out={k: v[0] for k, v in bufs[0].items()}, timing=True)
+            for k, v in r.stage_times().items():
+                stage.setdefault(k, []).append(v)
+        line["roofline"]["kernel_ms_isolated_frame"] = float(np.mean(stage["blend"]))
+        line["roofline"]["isolated_frame_stage_ms"] = {k: float(np.mean(v)) for k, v in stage.items()}
+    if rank == 0 and world == 1 and a.config == 3 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(scene, cams[0])
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
