@@ -50,6 +50,28 @@ class GSplatLoader:
         self.opacities = torch.sigmoid(f32(opacity_logits)).reshape(-1, 1)   # :43-45
 
     @classmethod
+    def from_path(cls, path, device="cpu") -> "GSplatLoader":
+        """What ``GSplatLoader(path_to_gsplat, device)`` does in the reference (splat_utils.py:16-49), without
+        nerfstudio's ``eval_setup``: ``path`` is the splatfacto ``config.yml`` (its run directory holds
+        ``nerfstudio_models/step-*.ckpt``; the latest is read), a checkpoint, or a scene ``.json`` / ``.npz``."""
+        from pathlib import Path
+        from . import io
+        p = Path(path)
+        if p.suffix == ".json":
+            return cls.from_json(p, device)
+        if p.suffix == ".npz":
+            d = io.load_npz(p)
+            return cls(d["means"], d["quats"], d["scales"], d["features_dc"], d["opacities"], device)
+        if p.suffix != ".ckpt":
+            run = p.parent if p.is_file() or p.suffix in (".yml", ".yaml") else p
+            ckpts = sorted((run / "nerfstudio_models").glob("step-*.ckpt"))
+            if not ckpts:
+                raise FileNotFoundError(f"no nerfstudio_models/step-*.ckpt next to {path}")
+            p = ckpts[-1]
+        g = io.load_splatfacto_ckpt(p)
+        return cls(g["means"], g["quats"], g["scales"], g["features_dc"], g["opacities"], device)
+
+    @classmethod
     def from_json(cls, path, device="cpu") -> "GSplatLoader":
         """``load_gsplat_from_json`` (splat_utils.py:51-89): keys means, rotations, colors, opacities,
         scalings; ``colors`` are taken as given, opacities get a sigmoid, scalings an exp."""

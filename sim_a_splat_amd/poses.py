@@ -37,6 +37,49 @@ def matrix_to_quat_wxyz(R: np.ndarray) -> np.ndarray:
     return q / np.linalg.norm(q)
 
 
+class SO3:
+    """The two members of ``viser.transforms.SO3`` the reference's render path touches: ``.wxyz`` and
+    ``.as_matrix()``."""
+
+    def __init__(self, wxyz: Sequence[float]):
+        self.wxyz = np.asarray(wxyz, dtype=np.float64).reshape(4)
+
+    def as_matrix(self) -> np.ndarray:
+        return quat_wxyz_to_matrix(self.wxyz)
+
+
+class SE3:
+    """Stand-in for ``viser.transforms.SE3`` as the reference's camera dictionaries use it
+    (examples/demo_pusht_splat.py:54-78: ``tf.SE3(wxyz_xyz=...)``; read back through
+    ``.rotation().wxyz`` and ``.translation()``, splat_env_wrapper.py:56-63,153-154).  A real viser
+    SE3 works wherever this one does: everything downstream goes through ``pose_wxyz_xyz``."""
+
+    def __init__(self, wxyz_xyz: Sequence[float]):
+        v = np.asarray(wxyz_xyz, dtype=np.float64).reshape(7)
+        self.wxyz_xyz = v
+
+    def rotation(self) -> SO3:
+        return SO3(self.wxyz_xyz[:4])
+
+    def translation(self) -> np.ndarray:
+        return self.wxyz_xyz[4:].copy()
+
+
+def pose_wxyz_xyz(pose) -> Tuple[np.ndarray, np.ndarray]:
+    """(wxyz [4], xyz [3]) of a camera / frame pose given as an SE3-like object (``.rotation().wxyz`` and
+    ``.translation()``: viser.transforms.SE3 or ``poses.SE3``), a ``(wxyz, xyz)`` pair, or a flat 7-vector."""
+    if hasattr(pose, "rotation") and hasattr(pose, "translation"):
+        rot = pose.rotation() if callable(pose.rotation) else pose.rotation
+        tr = pose.translation() if callable(pose.translation) else pose.translation
+        return np.asarray(rot.wxyz, dtype=np.float64).reshape(4), np.asarray(tr, dtype=np.float64).reshape(3)
+    if isinstance(pose, (tuple, list)) and len(pose) == 2:
+        return np.asarray(pose[0], dtype=np.float64).reshape(4), np.asarray(pose[1], dtype=np.float64).reshape(3)
+    v = np.asarray(pose, dtype=np.float64).reshape(-1)
+    if v.shape != (7,):
+        raise TypeError("pose must be SE3-like, a (wxyz, xyz) pair or a 7-vector wxyz_xyz")
+    return v[:4].copy(), v[4:].copy()
+
+
 def decompose_icp(icp: np.ndarray, tol: float = 1e-6) -> Tuple[float, np.ndarray, np.ndarray]:
     """Uniform scale, rotation and translation of the saved ICP 4x4 (splat_handler.py:66-83).
     Raises ValueError where the reference asserts (non-uniform scale / shear)."""

@@ -50,3 +50,38 @@ def twin_scene_kwargs(g):
     if g["group_id"].size:
         kw["group_id"] = g["group_id"]
     return g["means"], g["opacities"], g["colors"], kw
+
+
+# ---- stand-ins for the handful of viser attributes ViserBridge uses (viser is absent from this image) ----
+class FakeViserCamera:
+    def __init__(self):
+        import numpy as np
+        self.wxyz, self.position, self.fov, self.aspect = np.array([0.0, 1.0, 0, 0]), np.array([0.0, 0, 3.0]), 1.2, 4 / 3
+        self._cbs = []
+
+    def on_update(self, cb):
+        self._cbs.append(cb)
+
+    def move(self, position):
+        import numpy as np
+        self.position = np.asarray(position, float)
+        for cb in self._cbs:
+            cb(self)
+
+
+class FakeViserClient:
+    def __init__(self, cid):
+        import types
+        self.client_id, self.camera, self.images = cid, FakeViserCamera(), []
+        self.scene = types.SimpleNamespace(set_background_image=lambda img, **kw: self.images.append((img, kw)))
+
+
+class FakeViserServer:
+    def __init__(self):
+        self.connect, self.disconnect = [], []
+
+    def on_client_connect(self, cb):
+        self.connect.append(cb)
+
+    def on_client_disconnect(self, cb):
+        self.disconnect.append(cb)

@@ -8,6 +8,7 @@ import torch
 import oracle
 from oracle import ref_math
 from sim_a_splat_amd import poses
+from sim_a_splat_amd.poses import SE3
 from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND as BG
 from sim_a_splat_amd.synthetic import c2w_opengl_from_viewmat, make_scene, ring_camera
 
@@ -110,7 +111,7 @@ def test_door_b_handler_groups_and_get_render():
         T[:3, :3] = ref_math.quat_wxyz_to_R(rng.normal(size=4))
         T[:3, 3] = rng.normal(0, 0.05, size=3)
         fk.append(T)
-    h = SplatHandler(sc.means, covs, colors, sc.opacities, masks, icp, fk, device=0)
+    h = SplatHandler.from_arrays(sc.means, covs, colors, sc.opacities, masks, icp, fk, device=0)
     msg = _fake_msg(rng, K_links)
     h.draw_handler(msg)
     rig = CameraRig({0: {"link_name": "world", "local_frame": ((0.0, 1.0, 0.0, 0.0), (0.0, 0.0, 3.0)), "type": "viewport", "render_size": [60, 80]},
@@ -161,11 +162,11 @@ def test_door_b_with_the_shipped_masks_and_icp(golden_dir):
                      f'<origin xyz="0.05 0 0.1" rpy="{0.3 * i} 0 0"/><axis xyz="0 0 1"/></joint>' for i in range(1, 7))
     fk = urdf_fk.visual_mesh_fk(urdf_fk.load(f"<robot>{chain}</robot>"), a["joint_config"])
     assert len(fk) == 7
-    h = SplatHandler(sc.means, covs, colors, sc.opacities, masks, a["icp_transformation"], fk, device=0)
+    h = SplatHandler.from_arrays(sc.means, covs, colors, sc.opacities, masks, a["icp_transformation"], fk, device=0)
     msg = _fake_msg(rng, 7)
     h.draw_handler(msg)
     cam_q, cam_p = (0.0, 1.0, 0.0, 0.0), (0.0, 0.0, 3.0)
-    frame = h.render([(np.array(cam_q), np.array(cam_p))], [[480, 640]])[0]
+    frame = h.render(h.scene, [(np.array(cam_q), np.array(cam_p))], [[480, 640]])[0]
     assert frame.shape == (480, 640, 3) and frame.dtype == np.uint8
     # oracle: registration order = links (a Gaussian in two masks is registered twice), then the rest
     idx = [np.nonzero(masks[f"link{i}"])[0] for i in range(7)]
@@ -217,7 +218,7 @@ def test_handler_from_assets_files(golden_dir, tmp_path):
     msg = _fake_msg(rng, 7)
     h.draw_handler(msg)
     cam_q, cam_p = (0.0, 1.0, 0.0, 0.0), (0.0, 0.0, 3.0)
-    frame = h.render([(np.array(cam_q), np.array(cam_p))], [[120, 160]])[0]
+    frame = h.render(h.scene, [SE3(np.concatenate((cam_q, cam_p)))], [[120, 160]])[0]
     # oracle on the same crop and registration order
     keep = aabb_mask(sc.means, bounds)
     assert 0.3 * n < keep.sum() < n
@@ -237,4 +238,131 @@ def test_handler_from_assets_files(golden_dir, tmp_path):
     ref = oracle.render(means[order], ops[order], cols[order], V, K, 160, 120, cov6=cov6, sh_degree=-1, group_id=group_of,
                         group_Rt=np.stack(Rt), background=(0, 0, 0), want_rgb8=True)
     assert ref["n_visible"] > 500 and np.array_equal(frame, ref["rgb8"])
+    h.scene.close()
+
+
+def _door_b_setup(n, seed, k_links):
+    """A synthetic Door-B scene: Gaussians with 3x3 covariances + RGB, `k_links` link masks, an ICP similarity
+    and FK poses; returns what SplatHandler.from_arrays takes and what the oracle needs to follow it."""
+    from sim_a_splat_amd.covariance import compute_cov, sh2rgb
+    rng = np.random.default_rng(seed)
+    sc = make_scene(n, seed=seed, log_scale_mean=float(np.log(0.03)))
+    covs = compute_cov(torch.from_numpy(sc.quats), torch.from_numpy(sc.scales)).numpy()
+    colors = np.clip(sh2rgb(torch.from_numpy(sc.sh[:, 0])).numpy(), 0, 1)
+    gid = rng.integers(0, k_links + 1, size=sc.n)                      # k_links = "no link"
+    masks = {f"link{i}": gid == i for i in range(k_links)}
+    icp = np.eye(4)
+    icp[:3, :3] = 0.9 * ref_math.quat_wxyz_to_R(rng.normal(size=4))
+    icp[:3, 3] = [0.02, -0.01, 0.03]
+    fk = []
+    for _ in range(k_links):
+        T = np.eye(4)
+        T[:3, :3] = ref_math.quat_wxyz_to_R(rng.normal(size=4))
+        T[:3, 3] = rng.normal(0, 0.05, size=3)
+        fk.append(T)
+    order = np.concatenate([np.nonzero(gid == i)[0] for i in range(k_links + 1)])
+    group_of = np.concatenate([np.full((gid == i).sum(), i, np.uint8) for i in range(k_links + 1)])
+    cov6 = np.stack([covs[:, 0, 0], covs[:, 0, 1], covs[:, 0, 2], covs[:, 1, 1], covs[:, 1, 2], covs[:, 2, 2]], 1)
+    return dict(sc=sc, covs=covs, colors=colors, masks=masks, icp=icp, fk=fk, order=order, group_of=group_of, cov6=cov6, rng=rng)
+
+
+def _oracle_door_b(d, msg, wxyz, pos, H, W, fov, scene):
+    s, Ri, ti = poses.decompose_icp(d["icp"])
+    Rt = []
+    for i in range(len(d["fk"])):
+        R, t = ref_math.link_splat_pose(Ri, ti, s, d["fk"][i][:3, :3], d["fk"][i][:3, 3], msg.quaternion[i], msg.position[i])
+        Rt.append(poses.rt_to_row12(poses.quat_wxyz_to_matrix(poses.matrix_to_quat_wxyz(R)), t))   # the handle stores a quaternion
+    Rt.append(poses.rt_to_row12(np.eye(3), np.zeros(3)))
+    V, K = scene._view_and_K(H, W, wxyz, pos, fov)
+    o, sc = d["order"], d["sc"]
+    return oracle.render(sc.means[o], sc.opacities[o], d["colors"][o], V, K, W, H, cov6=d["cov6"][o], sh_degree=-1,
+                         group_id=d["group_of"], group_Rt=np.stack(Rt), background=(0, 0, 0), want_rgb8=True)
+
+
+def test_splat_env_wrapper_step_against_the_oracle():
+    """SplatEnvWrapper (row a11) end to end on the GPU: reset, two steps with the reference's camera dictionary
+    (SE3 local frames, a viewport and an eye-in-hand camera of one size -> one batched render): every
+    camera_i of every step equals the oracle's uint8 frame for that step's link poses and camera pose."""
+    from sim_a_splat_amd.env_wrapper import SplatEnvWrapper
+    from sim_a_splat_amd.handler import SplatHandler
+    K_links = 3
+    d = _door_b_setup(5000, 303, K_links)
+    h = SplatHandler.from_arrays(d["sc"].means, d["covs"], d["colors"], d["sc"].opacities, d["masks"], d["icp"], d["fk"], device=0)
+
+    class Inner:
+        visualize_robot_flag = False
+
+        def __init__(self):
+            self.msgs = [_fake_msg(np.random.default_rng(50 + k), K_links) for k in range(3)]
+            self.t = 0
+
+        def reset(self, seed=None, reset_to_state=None):
+            self.t = 0
+
+        def step(self, action):
+            self.t += 1
+            return {}, 0.0, False, False, {}
+
+        def render(self):
+            pass
+
+        def _get_obs(self):
+            return {"robot_pos": np.zeros(2)}
+
+        def _generate_draw_msg(self):
+            return self.msgs[self.t]
+
+        def close(self):
+            pass
+
+    inner = Inner()
+    env = SplatEnvWrapper(inner, splat_handler=h)
+    info = {0: {"link_name": "world", "local_frame": SE3(wxyz_xyz=np.array([0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 3.0])), "type": "viewport",
+                "render_size": [60, 80]},
+            1: {"link_name": "link2", "local_frame": SE3(wxyz_xyz=np.array([0.0, 1.0, 0.0, 0.0, 0.0, 0.1, 2.8])), "type": "moving",
+                "render_size": [60, 80]}}
+    env._configure_cameras(info)
+    env.reset()
+    for t in (1, 2):
+        obs, *_ = env.step(None)
+        msg = inner.msgs[t]
+        cam_poses = [h.get_attached_frame("link2", info[1]["local_frame"], msg), poses.pose_wxyz_xyz(info[0]["local_frame"])]
+        for i, (wxyz, pos) in enumerate(cam_poses):          # camera_0 = the moving camera, camera_1 = the viewport
+            ref = _oracle_door_b(d, msg, wxyz, pos, 60, 80, h.scene.camera.fov, h.scene)
+            assert np.array_equal(np.moveaxis(obs[f"camera_{i}"], 0, -1), ref["rgb8"]), (t, i)
+        assert obs["camera_1"].max() > 30                    # the viewport sees the scene
+    env.close()
+
+
+def test_viser_bridge_pushes_hip_frames_of_the_client_camera():
+    """Row f4 on the GPU: ViserBridge over a real SplatScene and the stand-in server -- the background image
+    pushed to a client is the HIP frame of THAT client's camera (pose, vertical fov, aspect -> width / K) and
+    equals the oracle's uint8 frame; a camera update and a group-pose change + refresh() push new frames."""
+    from conftest import FakeViserClient, FakeViserServer
+    from sim_a_splat_amd.handler import SplatHandler
+    from sim_a_splat_amd.viser_bridge import ViserBridge
+    K_links = 2
+    d = _door_b_setup(4000, 404, K_links)
+    h = SplatHandler.from_arrays(d["sc"].means, d["covs"], d["colors"], d["sc"].opacities, d["masks"], d["icp"], d["fk"], device=0)
+    msg0 = _fake_msg(np.random.default_rng(1), K_links)
+    h.draw_handler(msg0)
+    server = FakeViserServer()
+    bridge = ViserBridge(server, h.scene, height=90, max_width=400)
+    client = FakeViserClient(7)
+    client.camera.fov, client.camera.aspect = 0.9, 1.6                # -> 144 x 90
+    server.connect[0](client)                                          # a browser connects
+    img, kw = client.images[-1]
+    assert img.shape == (90, 144, 3) and img.dtype == np.uint8 and kw["format"] == "jpeg"
+    ref = _oracle_door_b(d, msg0, client.camera.wxyz, client.camera.position, 90, 144, 0.9, h.scene)
+    assert ref["n_visible"] > 100 and np.array_equal(img, ref["rgb8"])
+    client.camera.move([0.3, -0.2, 2.5])                               # the user orbits: on_update -> a new frame
+    ref = _oracle_door_b(d, msg0, client.camera.wxyz, client.camera.position, 90, 144, 0.9, h.scene)
+    assert len(client.images) == 2 and np.array_equal(client.images[-1][0], ref["rgb8"])
+    msg1 = _fake_msg(np.random.default_rng(2), K_links)
+    h.draw_handler(msg1)                                               # the robot moves
+    assert bridge.refresh() == 1
+    ref = _oracle_door_b(d, msg1, client.camera.wxyz, client.camera.position, 90, 144, 0.9, h.scene)
+    assert np.array_equal(client.images[-1][0], ref["rgb8"]) and not np.array_equal(client.images[-1][0], client.images[-2][0])
+    server.disconnect[0](client)
+    assert bridge.refresh() == 0
     h.scene.close()
