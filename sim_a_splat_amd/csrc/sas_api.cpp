@@ -65,6 +65,7 @@ struct Slot {
     Scratch scr;
     SasCam cam{};
     bool busy = false, timed = false, timed_tiles = false;
+    int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
     // per-frame parameter block (pinned host mirror + device copy)
     SasParams *params_host = nullptr;
     DevBuf params_dev;
@@ -96,6 +97,9 @@ struct sas_ctx {
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
+    // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
+    // cameras) in groups that share one set of launches (grid.y = view).  SAS_GROUP=1 disables, 2..4 sets the size.
+    int group_views = -1;           // -1: half of the slots (two groups can be in flight)
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
@@ -402,21 +406,83 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     return SAS_OK;
 }
 
+// Enqueue n same-sized views (consecutive idle slots sl[0..n-1], args filled) as ONE launch group on the leader's
+// stream: per-view parameter / counter uploads, then one projection, one scan, one scatter and one tile launch
+// with grid.y = view.  A Gym step's cameras on a small scene are launch-bound (~25 runtime calls and four
+// 10-30 us kernels per camera); the group needs 3 n + 10 calls and its kernels fill more of the chip.
+int enqueue_group(sas_ctx *c, Slot **sl, int n)
+{
+    int rc;
+    for (int k = 0; k < n; ++k)
+        if ((rc = prepare_frame(c, *sl[k]))) return rc;
+    Slot &ld = *sl[0];
+    hipStream_t st = ld.fs;
+    const RenderArgs &a = ld.args;
+    const int tiles = ld.cam.tw * ld.cam.th;
+    SasMulti mf{};
+    mf.nv = n;
+    for (int k = 0; k < n; ++k) {
+        mf.f[k] = frame_of(c, sl[k]->scr, tiles);
+        mf.P[k] = (const SasParams *)sl[k]->params_dev.p;
+        HIP_TRY(c, hipMemcpyAsync(sl[k]->params_dev.p, sl[k]->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(sl[k]->scr.counters.p, 0, counter_bytes(tiles), st));
+    }
+    if (c->scene.group_Rt)
+        HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipEventRecord(ld.start, a.stream));
+    sas_launch_project_multi(st, c->scene, mf);
+    sas_launch_scan_multi(st, tiles, mf);
+    sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);
+    HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel (enqueue_body)
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
+    bool any_fill = false;
+    for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
+    sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill,
+                                ttiles ? ld.ev[4] : nullptr, ttiles ? ld.ev[5] : nullptr);
+    for (int k = 0; k < n; ++k) {
+        const RenderArgs &ak = sl[k]->args;
+        const bool fill = ak.depth && (ak.flags & SAS_DEPTH_FILL_MAX);
+        const bool pts = ak.depth && (ak.points || ak.mask);
+        if (fill || pts) sas_launch_depth_tail(st, tiles, mf.P[k], mf.f[k], fill, pts);
+    }
+    HIP_TRY(c, hipEventRecord(ld.gpu_done, st));
+    for (int k = 0; k < n; ++k)
+        HIP_TRY(c, hipMemcpyAsync(sl[k]->stats_host, sl[k]->scr.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ld.done, st));
+    for (int k = 0; k < n; ++k) {
+        sl[k]->busy = true;
+        sl[k]->timed = false;
+        sl[k]->timed_tiles = false;
+        sl[k]->group = k == 0 ? n : 0;
+    }
+    ld.timed_tiles = ttiles;
+    c->has_frame = true;
+    return SAS_OK;
+}
+
 // Verify the oldest in-flight frame; on overflow grow its intersection buffer and render it again.
 int complete_oldest(sas_ctx *c)
 {
     if (c->inflight <= 0) return SAS_OK;
     Slot &sl = c->slots[c->head];
+    const int g = sl.group > 1 ? sl.group : 1;   // a launch group completes as a whole (one stream, one done event)
+    Slot *mem[SAS_MAX_GROUP];
+    for (int k = 0; k < g; ++k) mem[k] = &c->slots[(c->head + k) % c->n_slots];
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIP_TRY(c, hipEventSynchronize(sl.done));
-        const unsigned *s = sl.stats_host;
-        c->stats[SAS_S_NVISIBLE] = s[0];
-        c->stats[SAS_S_NISECT] = s[1];
-        c->stats[SAS_S_MAX_TILE_LEN] = s[4];
-        c->stats[SAS_S_CAPACITY] = sl.scr.cap;
-        c->stats[SAS_S_REGROWS] = c->regrows;
-        c->stats[SAS_S_WINDOW_MISSES] = s[5];
-        c->stats[SAS_S_FALLBACK_TILES] = s[6];
+        bool overflow = false;
+        for (int k = 0; k < g; ++k) {
+            const unsigned *s = mem[k]->stats_host;
+            c->stats[SAS_S_NVISIBLE] = s[0];
+            c->stats[SAS_S_NISECT] = s[1];
+            c->stats[SAS_S_MAX_TILE_LEN] = s[4];
+            c->stats[SAS_S_CAPACITY] = mem[k]->scr.cap;
+            c->stats[SAS_S_REGROWS] = c->regrows;
+            c->stats[SAS_S_WINDOW_MISSES] = s[5];
+            c->stats[SAS_S_FALLBACK_TILES] = s[6];
+            overflow = overflow || s[2] != 0;
+        }
         if (sl.timed) {
             for (int k = 0; k < 6; ++k) (void)hipEventElapsedTime(&c->stage_ms[k], sl.ev[k], sl.ev[k + 1]);
             (void)hipEventElapsedTime(&c->stage_ms[SAS_T_TOTAL], sl.ev[0], sl.ev[6]);
@@ -430,26 +496,33 @@ int complete_oldest(sas_ctx *c)
                 c->stage_frames++;
             }
         }
-        if (!s[2]) {
+        if (!overflow) {
             // Only now -- the host has seen that the frame did not overflow its intersection buffer -- is
             // later work on the caller's stream ordered behind the frame (the wait is already satisfied: a
             // no-op on the GPU).  Releasing the caller's stream any earlier would let a stream-ordered
             // consumer read a truncated frame that is about to be rendered again.
             HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
-            sl.busy = false;
-            c->head = (c->head + 1) % c->n_slots;
-            c->inflight--;
-            c->frames_completed++;
+            for (int k = 0; k < g; ++k) {
+                mem[k]->busy = false;
+                mem[k]->group = 1;
+            }
+            c->head = (c->head + g) % c->n_slots;
+            c->inflight -= g;
+            c->frames_completed += g;
             return SAS_OK;
         }
-        // intersection buffer too small: grow to the measured need (+25 %) and render the frame again
-        const long long need = (long long)s[1];
-        const long long want = need + need / 4 + 1024;
-        if (want > sl.scr.cap) sl.scr.cap = want;
-        for (Slot &o : c->slots)   // the other slot will need it too
+        // intersection buffer too small: grow to the measured need (+25 %) and render the frame (group) again
+        long long want = 0;
+        for (int k = 0; k < g; ++k) {
+            const long long need = (long long)mem[k]->stats_host[1];
+            want = std::max(want, need + need / 4 + 1024);
+        }
+        for (int k = 0; k < g; ++k)
+            if (want > mem[k]->scr.cap) mem[k]->scr.cap = want;
+        for (Slot &o : c->slots)   // the other slots will need it too
             if (o.scr.cap && o.scr.cap < want && !o.busy) o.scr.cap = want;
         c->regrows++;
-        int rc = enqueue_frame(c, sl);
+        int rc = g > 1 ? enqueue_group(c, mem, g) : enqueue_frame(c, sl);
         if (rc) return rc;
     }
     return fail(c, SAS_ERR_HIP, "intersection buffer kept overflowing");
@@ -487,6 +560,10 @@ int sas_create(int device, sas_ctx **out)
     }
     if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
     if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("SAS_GROUP")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
+    }
     ok = ok && hipHostMalloc((void **)&c->groups_pinned, sizeof(float) * 12 * 256) == hipSuccess;
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
@@ -696,9 +773,10 @@ static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, c
     a.valid = true;
 }
 
-// One view (n == 1) or a pair of views that share one projection pass (n == 2).
+// One view (n == 1), a pair of views that share one projection pass (n == 2), or -- `grouped` -- up to
+// SAS_MAX_GROUP views that share every launch (enqueue_group).
 static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int height, const float *background,
-                        unsigned flags, const float *max_depth, void *stream)
+                        unsigned flags, const float *max_depth, void *stream, bool grouped = false)
 {
     if (!c) return SAS_ERR_INVALID;
     for (int k = 0; k < n; ++k) {
@@ -716,10 +794,19 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
         if (rc) return rc;
     }
     c->stream = st;
-    Slot *sl[2] = {nullptr, nullptr};
+    Slot *sl[SAS_MAX_GROUP] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < n; ++k) {
         sl[k] = &c->slots[(c->head + c->inflight + k) % c->n_slots];
         fill_args(sl[k]->args, views[k], width, height, background, flags, max_depth, st);
+    }
+    if (grouped) {
+        const int rc = enqueue_group(c, sl, n);
+        if (rc) return rc;
+        c->inflight += n;
+        c->frames_submitted += n;
+        c->last_slot = (int)(sl[n - 1] - c->slots);
+        if (flags & SAS_ASYNC) return SAS_OK;
+        return complete_all(c);
     }
     if (n == 2) {
         for (int k = 0; k < 2; ++k) {
@@ -777,7 +864,20 @@ int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float
     // (timed and full-sort frames keep to one view per pass).
     const bool want_pairs = c->pair_views < 0 ? c->scene.n >= sas_ctx::kPairMinGaussians : c->pair_views != 0;
     const bool pair = want_pairs && c->n_slots >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
+    // small scenes (not paired): launch groups, by default half of the slots each so that two can be in flight
+    int gsz = c->group_views > 0 ? c->group_views : std::max(2, c->n_slots / 2);
+    gsz = std::min(std::min(gsz, SAS_MAX_GROUP), c->n_slots);
+    const bool group = !pair && gsz >= 2 && n_views >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
     for (int v = 0; v < n_views;) {
+        if (group && v + 1 < n_views) {
+            const int n = std::min(gsz, n_views - v);
+            ViewCall vc[SAS_MAX_GROUP];
+            for (int k = 0; k < n; ++k) vc[k] = view(v + k);
+            int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream, true);
+            if (rc) return rc;
+            v += n;
+            continue;
+        }
         const int n = (pair && v + 1 < n_views) ? 2 : 1;
         const ViewCall vc[2] = {view(v), view(n == 2 ? v + 1 : v)};
         int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream);

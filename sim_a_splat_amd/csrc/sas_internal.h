@@ -76,6 +76,15 @@ struct SasParams {
     SasOutputs out;
 };
 
+// Up to SAS_MAX_GROUP same-sized views rendered by ONE set of launches (grid.y = view): the cameras of a Gym
+// step.  Passed to the *_multi kernels by value.
+#define SAS_MAX_GROUP 4
+struct SasMulti {
+    SasFrame f[SAS_MAX_GROUP];
+    const SasParams *P[SAS_MAX_GROUP];
+    int nv;
+};
+
 // launchers (sas_kernels.hip)
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
@@ -86,6 +95,13 @@ void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, c
 void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams *P0, const SasFrame &f0, const SasParams *P1,
                          const SasFrame &f1);
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f);
+// one launch for all views of a group (same image size): project (one pass over the scene per view), scan,
+// scatter, lazy tile kernel
+void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti &mf);
+void sas_launch_scan_multi(hipStream_t st, int tiles, const SasMulti &mf);
+void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf);
+void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
+                                 hipEvent_t ev_start, hipEvent_t ev_stop);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f);
 struct SasSortStreams {
     hipStream_t side[2];   // nullptr: run the classes back to back on the frame's stream

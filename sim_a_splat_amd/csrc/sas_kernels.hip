@@ -297,7 +297,7 @@ DEV float4 scene_load(const float4 *p)
 }
 
 template <int DEG, int NV>
-__global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
+DEV void project_body(const SasScene &s, const ViewSet &vs)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < s.n;
@@ -425,6 +425,22 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
     for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.P[v]->cam.tw, g[v], s_win, s_hist, &s_nvis);
 }
 
+template <int DEG, int NV>
+__global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
+{
+    project_body<DEG, NV>(s, vs);
+}
+
+// all views of a group in one launch: blockIdx.y = view, one pass over the (small) scene per view
+template <int DEG>
+__global__ __launch_bounds__(256) void k_project_multi(SasScene s, SasMulti mf)
+{
+    ViewSet vs;
+    vs.P[0] = vs.P[1] = mf.P[blockIdx.y];
+    vs.f[0] = vs.f[1] = mf.f[blockIdx.y];
+    project_body<DEG, 1>(s, vs);
+}
+
 // ---- k_scan: exclusive scan over tiles (workgroup 0) + tile order (workgroup 1) -------------------
 // Each thread owns 8 consecutive tiles per round and loads them before anything else, so a round
 // costs one memory latency (the counts were written by memory-side atomics and miss every cache).
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
 // start early and short ones fill the tail), visible count, max list length, overflow flag.
 constexpr int kScanPer = 8;
 
-__global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
+DEV void scan_body(const SasFrame &f, int tiles)
 {
     __shared__ int wsum[16];
     __shared__ int s_bucket[33];
@@ -547,12 +563,15 @@ __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles)
     }
 }
 
+__global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles) { scan_body(f, tiles); }
+__global__ __launch_bounds__(1024) void k_scan_multi(SasMulti mf, int tiles) { scan_body(mf.f[blockIdx.y], tiles); }
+
 // ---- k_scatter: T3 emit ---------------------------------------------------------------------------
 // Same window as k_project: count in LDS, reserve one contiguous run per touched tile with a
 // single returning global atomic, then rank inside the run with LDS atomics.  Key = depth bits << 32
 // | storage slot; the rare runs of identical depth are ordered by the caller's index (perm[slot])
 // when a tile is sorted, exactly as the reference's stable sort orders them.
-__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f)
+DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
 {
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
@@ -593,6 +612,9 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f)
         if ((long long)pos < f.cap) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
     });
 }
+
+__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body(s, tw, f); }
+__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
 
 }  // namespace
 
@@ -638,6 +660,30 @@ void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams *P0,
     vs.P[0] = P0; vs.P[1] = P1;
     vs.f[0] = f0; vs.f[1] = f1;
     launch_project<2>(st, s, vs);
+}
+
+void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti &mf)
+{
+    if (s.n <= 0) return;
+    const dim3 grid((unsigned)((s.n + 255) / 256), (unsigned)mf.nv);
+    switch (s.sh_degree) {
+        case 0: hipLaunchKernelGGL((k_project_multi<0>), grid, dim3(256), 0, st, s, mf); break;
+        case 1: hipLaunchKernelGGL((k_project_multi<1>), grid, dim3(256), 0, st, s, mf); break;
+        case 2: hipLaunchKernelGGL((k_project_multi<2>), grid, dim3(256), 0, st, s, mf); break;
+        case 3: hipLaunchKernelGGL((k_project_multi<3>), grid, dim3(256), 0, st, s, mf); break;
+        default: hipLaunchKernelGGL((k_project_multi<-1>), grid, dim3(256), 0, st, s, mf); break;
+    }
+}
+
+void sas_launch_scan_multi(hipStream_t st, int tiles, const SasMulti &mf)
+{
+    hipLaunchKernelGGL(k_scan_multi, dim3(2, (unsigned)mf.nv), dim3(1024), 0, st, mf, tiles);
+}
+
+void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf)
+{
+    if (s.n <= 0) return;
+    hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 255) / 256), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
 }
 
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)

@@ -792,8 +792,7 @@ constexpr int kRankMax = SAS_TUNE_RANKMAX;   // largest depth bucket a chunk is 
 constexpr int kLazyThreads = 256;
 
 template <bool FAST_EXP, bool WANT_MAX>
-__global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC))) void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
-                                                             const int *perm)
+DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm)
 {
     // timing experiments only (-DSAS_TUNE_ABLATE=1: no chunk sort, =2: no compositing): wrong images
 #ifdef SAS_TUNE_ABLATE
@@ -1007,6 +1006,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads
 #endif
 }
 
+#define SAS_LAZY_ATTRS __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC)))
+template <bool FAST_EXP, bool WANT_MAX>
+__global__ SAS_LAZY_ATTRS void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss, const int *perm)
+{
+    tile_lazy_body<FAST_EXP, WANT_MAX>(P, f, n_gauss, perm);
+}
+// all views of a group in one launch: blockIdx.y = view
+template <bool FAST_EXP, bool WANT_MAX>
+__global__ SAS_LAZY_ATTRS void k_tile_lazy_multi(SasMulti mf, long long n_gauss, const int *perm)
+{
+    tile_lazy_body<FAST_EXP, WANT_MAX>(mf.P[blockIdx.y], mf.f[blockIdx.y], n_gauss, perm);
+}
+
 // Depth tail, one pass over the depth image after the tile kernel.
 // FILL: depth = where(alpha > 0, ED, max ED)  (T0).  alpha == 0 <=> nothing blended <=> ED == 0.
 //   Every workgroup first reduces the per-tile maxima (a few KB, L2-resident): no extra launch,
@@ -1133,6 +1145,29 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
     } else {
         if (want_max) launch_lazy<false, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
         else launch_lazy<false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+    }
+}
+
+template <bool FAST, bool WMAX>
+static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, long long n, const int *perm, hipEvent_t e0, hipEvent_t e1)
+{
+    if (e0 && e1)
+        hipExtLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX>), grid, dim3(kLazyThreads), 0, st, e0, e1, 0, mf, n, perm);
+    else
+        hipLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX>), grid, dim3(kLazyThreads), 0, st, mf, n, perm);
+}
+
+void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
+                                 hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const dim3 grid((unsigned)tiles, (unsigned)mf.nv);
+    const long long n = s.n > 0 ? s.n : 1;
+    if (fast_exp) {
+        if (want_max) launch_lazy_multi<true, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+    } else {
+        if (want_max) launch_lazy_multi<false, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
     }
 }
 
