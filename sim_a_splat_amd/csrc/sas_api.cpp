@@ -247,6 +247,7 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
     f.wg_vis = (int *)q.wgvis.p;
     f.tile_max = (unsigned *)q.tilemax.p;
     f.n_wg = (int)((c->scene.n + 255) / 256);
+    f.n_tiles = tiles;
     return f;
 }
 
@@ -366,6 +367,7 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
     hp.out.points = a.points; hp.out.mask = a.mask;
     hp.out.max_depth = a.max_depth; hp.out.use_max_depth = a.use_max_depth ? 1 : 0;
+    hp.out.n_pixels = (long long)a.W * a.H;
     return SAS_OK;
 }
 
@@ -903,6 +905,22 @@ int sas_frames_completed(sas_ctx *c, int64_t *submitted, int64_t *completed)
     if (completed) *completed = c->frames_completed;
     return SAS_OK;
 }
+
+#ifdef SAS_DEBUG_BOUNDS
+extern "C" int sas_debug_bounds_kernels(unsigned long long *out, int reset);
+extern "C" int sas_debug_bounds_tiles(unsigned long long *out, int reset);
+/* Bounds-checked build only: out[0] = guarded accesses found out of range since the last reset (they were
+ * skipped, not executed), out[1..3] = code, index and limit of the first one (0 if none). */
+int sas_debug_bounds(unsigned long long *out, int reset)
+{
+    unsigned long long a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || sas_debug_bounds_kernels(a, reset) || sas_debug_bounds_tiles(b, reset)) return SAS_ERR_HIP;
+    const unsigned long long *first = a[0] ? a : b;
+    out[0] = a[0] + b[0];
+    out[1] = first[1]; out[2] = first[2]; out[3] = first[3];
+    return SAS_OK;
+}
+#endif
 
 int sas_stage_times(sas_ctx *c, float *ms, int n)
 {

@@ -13,6 +13,36 @@ constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
 
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// ---- bounds-checked build (-DSAS_DEBUG_BOUNDS; GPU AddressSanitizer is not available on this pool) ----------
+// SAS_IN(i, n, code) is `true` in the product build.  In the debug build it tests 0 <= i < n; a violation
+// is counted, its code and values are kept, and the guarded access is SKIPPED (no fault, the run goes on):
+// `if (SAS_IN(pos, cap, 12)) keys[pos] = key;`.  Read back through sas_debug_bounds() (sas_api.cpp).
+#ifdef SAS_DEBUG_BOUNDS
+static __device__ unsigned long long g_sas_bounds[4];   // [0] violations [1] first code [2] first index [3] first limit (per translation unit)
+DEV bool sas_in_bounds(long long i, long long n, int code)
+{
+    if (i >= 0 && i < n) return true;
+    if (atomicAdd(&g_sas_bounds[0], 1ull) == 0ull) {
+        g_sas_bounds[1] = (unsigned long long)code;
+        g_sas_bounds[2] = (unsigned long long)i;
+        g_sas_bounds[3] = (unsigned long long)n;
+    }
+    return false;
+}
+#define SAS_IN(i, n, code) sas_in_bounds((long long)(i), (long long)(n), (code))
+#define SAS_BOUNDS_ACCESSOR(name)                                                                              \
+    extern "C" int name(unsigned long long *out, int reset)                                                    \
+    {                                                                                                          \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sas_bounds), sizeof(g_sas_bounds)) != hipSuccess) return -1; \
+        unsigned long long z[4] = {0, 0, 0, 0};                                                                \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_sas_bounds), z, sizeof(z)) != hipSuccess) return -1;       \
+        return 0;                                                                                              \
+    }
+#else
+#define SAS_IN(i, n, code) true
+#define SAS_BOUNDS_ACCESSOR(name)
+#endif
+
 // 16-byte non-temporal (streaming) load
 DEV float4 nt_load(const float4 *p)
 {

@@ -56,6 +56,7 @@ struct SasFrame {
     int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup
     unsigned *tile_max;        // [tiles] per-tile max expected depth (bits), written when depth is filled
     int n_wg;
+    int n_tiles;               // tw * th
 };
 
 struct SasOutputs {
@@ -67,6 +68,7 @@ struct SasOutputs {
     uint8_t *mask;
     float max_depth;      // mask = depth < max_depth when use_max_depth, else all ones
     int use_max_depth;
+    long long n_pixels;   // W * H
 };
 
 // Per-frame parameters, resident in device memory (one block per frame slot, uploaded on the frame's

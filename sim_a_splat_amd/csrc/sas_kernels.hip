@@ -264,17 +264,21 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
         __syncthreads();
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
+                }
         __syncthreads();
         for (int b = threadIdx.x; b < w.area; b += 256) {
             const int cnt = s_hist[b];
-            if (cnt) atomicAdd(&f.tile_count[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww], cnt);
+            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
+            if (cnt && SAS_IN(tile, f.n_tiles, 102)) atomicAdd(&f.tile_count[tile], cnt);
         }
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
     for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
-                  [&](int tile, unsigned, unsigned) { atomicAdd(&f.tile_count[tile], 1); });
+                  [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_count[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
     if (threadIdx.x == 0) *s_nvis = 0;
@@ -590,11 +594,15 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
         __syncthreads();
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[(ty - w.Y0) * w.ww + (tx - w.X0)], 1);
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    if (SAS_IN(b, kHistBins, 111)) atomicAdd(&s_hist[b], 1);
+                }
         __syncthreads();
         for (int b = threadIdx.x; b < w.area; b += 256) {
             const int cnt = s_hist[b];
-            s_base[b] = cnt ? atomicAdd(&f.tile_cursor[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww], cnt) : 0;
+            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
+            s_base[b] = (cnt && SAS_IN(tile, f.n_tiles, 112)) ? atomicAdd(&f.tile_cursor[tile], cnt) : 0;
             s_hist[b] = 0;
         }
         __syncthreads();
@@ -602,14 +610,18 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    if (!SAS_IN(b, kHistBins, 113)) continue;
                     const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
-                    if (pos < f.cap) f.keys[pos] = key;
+                    // pos >= cap is the documented overflow path (the frame is rendered again); a position
+                    // beyond the tile's own segment would be a bug
+                    if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key;
                 }
     }
     const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
     for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
+        if (!SAS_IN(tile, f.n_tiles, 115)) return;
         const int pos = atomicAdd(&f.tile_cursor[tile], 1);
-        if ((long long)pos < f.cap) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
+        if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
     });
 }
 
@@ -617,6 +629,8 @@ __global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f)
 __global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
 
 }  // namespace
+
+SAS_BOUNDS_ACCESSOR(sas_debug_bounds_kernels)
 
 // ---- launchers -------------------------------------------------------------------------------------
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,

@@ -109,7 +109,7 @@ DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int
             const int i = base + 64 * b;
             if (b < nbu && i < m) {
                 const unsigned d = (hi32(k[b]) >> (8 * byte)) & 255u;
-                buf[dbase[d] + cnt[wv * 256 + d] + rank[b]] = k[b];
+                if (SAS_IN(dbase[d] + cnt[wv * 256 + d] + rank[b], m, 211)) buf[dbase[d] + cnt[wv * 256 + d] + rank[b]] = k[b];
             }
         }
         __syncthreads();
@@ -164,7 +164,7 @@ DEV void lds_bucket_rank_sort(unsigned long long *buf, int m, int b0, int shift,
     for (int j = 0; j < maxlen; ++j) {
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
-            if (j < len[u]) {
+            if (j < len[u] && SAS_IN(st[u] + j, m, 210)) {
                 const unsigned long long kj = buf[st[u] + j];
                 const unsigned hj = hi32(kj), hk = hi32(key[u]);
                 bool less = hj < hk;
@@ -177,7 +177,7 @@ DEV void lds_bucket_rank_sort(unsigned long long *buf, int m, int b0, int shift,
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NK; ++u)
-        if (len[u] > 0) buf[st[u] + rank[u]] = key[u];
+        if (len[u] > 0 && SAS_IN(st[u] + rank[u], m, 209)) buf[st[u] + rank[u]] = key[u];
     __syncthreads();
 }
 
@@ -554,7 +554,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         have = idx < count;
         if (have) {
             long long id = slot_at(idx);
-            if (id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
+            if (!SAS_IN(id, n_gauss, 201) || id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
             ra = f.rec[3 * id + 0];
             rb = f.rec[3 * id + 1];
             rc = f.rec[3 * id + 2];
@@ -626,7 +626,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                     const int bit = ((wv & 1) * 2 + (g & 1)) + 4 * ((wv >> 1) * 2 + (g >> 1));
                     const bool has = (me >> bit) & 1u;
                     const unsigned long long m = __ballot(has);
-                    if (has) wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
+                    if (has && SAS_IN(qn[g] + (int)__popcll(m & lt_mask), 256, 202))
+                        wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
                     qn[g] += (int)__popcll(m);
                 }
             }
@@ -640,7 +641,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             // (one wave alone cannot hide the two dependent LDS round trips of an entry); only the
             // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
             for (int k = 0; k < kmax; k += 2) {
-                const unsigned off0 = myq[k], off1 = myq[k + 1];
+                unsigned off0 = myq[k], off1 = myq[k + 1];
+                if (!SAS_IN(k + 1, 256, 203) || !SAS_IN(off0 >> 4, kStage, 204) || !SAS_IN(off1 >> 4, kStage, 205)) off0 = off1 = 256u << 4;
                 const float4 K0 = *reinterpret_cast<const float4 *>(q0b + off0);
                 const float4 H0 = *reinterpret_cast<const float4 *>(q1b + off0);
                 const float4 K1 = *reinterpret_cast<const float4 *>(q0b + off1);
@@ -705,6 +707,7 @@ DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int i
     const float a = 1.0f - p.T;
     const float ED = p.d / fmaxf(a, 1e-10f);
     const long long pix = (long long)iy * W + ix;
+    if (!SAS_IN(pix, o.n_pixels, 212)) return 0.0f;
     const float w = 1.0f - a;
     float v0 = p.r + w * o.bg[0], v1 = p.g + w * o.bg[1], v2 = p.b + w * o.bg[2];
     v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
@@ -818,6 +821,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     const unsigned long long t_wg0 = wall_clock64();
 #endif
     const int tile = f.tile_order[blockIdx.x];
+    if (!SAS_IN(tile, f.n_tiles, 213)) return;   // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
     int ox, oy;
@@ -894,7 +898,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (i0 + u * kLazyThreads + tid < n) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
+                if (i0 + u * kLazyThreads + tid < n && SAS_IN((dd[u] - dmin) >> shift, 256, 208)) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
         }
         __syncthreads();
         int b_next = 0;
@@ -958,8 +962,10 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 for (int u = 0; u < U; ++u) {
                     if (i0 + u * kLazyThreads + tid < n) {
                         const int b = (int)((hi32(kk[u]) - dmin) >> shift);
-                        if (b >= b0 && b <= b1)
-                            ck[atomicAdd(&s_cur[b], 1u)] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                        if (b >= b0 && b <= b1 && SAS_IN(b, 256, 206)) {
+                            const unsigned pos = atomicAdd(&s_cur[b], 1u);
+                            if (SAS_IN(pos, kChunk, 207)) ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                        }
                     }
                 }
             }
@@ -1064,6 +1070,27 @@ __global__ __launch_bounds__(256) void k_depth_tail(const unsigned *tile_max, in
 }
 
 }  // namespace
+
+SAS_BOUNDS_ACCESSOR(sas_debug_bounds_tiles)
+#ifdef SAS_DEBUG_BOUNDS
+// the checker checked: one guarded access that IS out of range (index 5 of 4) must be counted and skipped
+namespace {
+__global__ void k_bounds_selftest(int *hit)
+{
+    if (SAS_IN(5, 4, 999)) *hit = 1;
+}
+}  // namespace
+extern "C" int sas_debug_bounds_selftest(void)
+{
+    int *d = nullptr, h = 0;
+    if (hipMalloc(&d, sizeof(int)) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, sizeof(int));
+    hipLaunchKernelGGL(k_bounds_selftest, dim3(1), dim3(1), 0, nullptr, d);
+    const bool ok = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? h : -1;   // 0: the access was skipped
+}
+#endif
 
 // ---- launchers -------------------------------------------------------------------------------------
 constexpr int kSortMid = 4096, kSortLarge = 16384;
