@@ -640,17 +640,21 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             // Two queue entries per trip: their record loads, sigmas and exponentials are independent
             // (one wave alone cannot hide the two dependent LDS round trips of an entry); only the
             // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
-            for (int k = 0; k < kmax; k += 2) {
+            struct Trip { float4 K0, H0, K1, H1, C0, C1; };
+            auto load_trip = [&](Trip &t, int k) {
                 unsigned off0 = myq[k], off1 = myq[k + 1];
                 if (!SAS_IN(k + 1, 256, 203) || !SAS_IN(off0 >> 4, kStage, 204) || !SAS_IN(off1 >> 4, kStage, 205)) off0 = off1 = 256u << 4;
-                const float4 K0 = *reinterpret_cast<const float4 *>(q0b + off0);
-                const float4 H0 = *reinterpret_cast<const float4 *>(q1b + off0);
-                const float4 K1 = *reinterpret_cast<const float4 *>(q0b + off1);
-                const float4 H1 = *reinterpret_cast<const float4 *>(q1b + off1);
-                const float4 C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
-                const float4 C1 = *reinterpret_cast<const float4 *>(q2b + off1);
-                const float sg0 = fma_(H0.y, pc.xy, fma_(H0.x, pc.yy, fma_(K0.w, pc.xx, fma_(K0.z, pc.y, fma_(K0.y, p.x, K0.x)))));
-                const float sg1 = fma_(H1.y, pc.xy, fma_(H1.x, pc.yy, fma_(K1.w, pc.xx, fma_(K1.z, pc.y, fma_(K1.y, p.x, K1.x)))));
+                t.K0 = *reinterpret_cast<const float4 *>(q0b + off0);
+                t.H0 = *reinterpret_cast<const float4 *>(q1b + off0);
+                t.K1 = *reinterpret_cast<const float4 *>(q0b + off1);
+                t.H1 = *reinterpret_cast<const float4 *>(q1b + off1);
+                t.C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
+                t.C1 = *reinterpret_cast<const float4 *>(q2b + off1);
+            };
+            // returns true when every pixel of the wave has terminated
+            auto composite_trip = [&](const Trip &t) -> bool {
+                const float sg0 = fma_(t.H0.y, pc.xy, fma_(t.H0.x, pc.yy, fma_(t.K0.w, pc.xx, fma_(t.K0.z, pc.y, fma_(t.K0.y, p.x, t.K0.x)))));
+                const float sg1 = fma_(t.H1.y, pc.xy, fma_(t.H1.x, pc.yy, fma_(t.K1.w, pc.xx, fma_(t.K1.z, pc.y, fma_(t.K1.y, p.x, t.K1.x)))));
                 // Every decision below is a per-lane select on a value, not a wave mask combined on the
                 // scalar unit (which the CU's four SIMDs share: a scalar instruction costs as much issue time
                 // as a vector one).  A lane the splat does not reach has a large sigma: the contract's clamp
@@ -660,8 +664,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 float E0, E1;
                 if (FAST_EXP) { E0 = __expf(fmaxf(-sg0, -86.0f)); E1 = __expf(fmaxf(-sg1, -86.0f)); }
                 else { E0 = c_expf_neg(fmaxf(-sg0, -86.0f), sE5); E1 = c_expf_neg(fmaxf(-sg1, -86.0f), sE5); }
-                const float al0 = fminf(kMaxAlpha, H0.w * E0);
-                const float al1 = fminf(kMaxAlpha, H1.w * E1);
+                const float al0 = fminf(kMaxAlpha, t.H0.w * E0);
+                const float al1 = fminf(kMaxAlpha, t.H1.w * E1);
                 // first entry: weight w = alpha T (0 when skipped), next T = T - w
                 const float w0 = (al0 < kAlphaThr) ? 0.0f : al0 * p.T;
                 const float nT0 = p.T - w0;
@@ -677,17 +681,23 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 const bool stop1 = nT1 <= kTStop;
                 const float vis1 = stop1 ? 0.0f : w1;
                 p.T = stop1 ? Tm : nT1;
-                p.r = fma_(C1.x, vis1, fma_(C0.x, vis0, p.r));
-                p.g = fma_(C1.y, vis1, fma_(C0.y, vis0, p.g));
-                p.b = fma_(C1.z, vis1, fma_(C0.z, vis0, p.b));
-                p.d = fma_(C1.w, vis1, fma_(C0.w, vis0, p.d));
+                p.r = fma_(t.C1.x, vis1, fma_(t.C0.x, vis0, p.r));
+                p.g = fma_(t.C1.y, vis1, fma_(t.C0.y, vis0, p.g));
+                p.b = fma_(t.C1.z, vis1, fma_(t.C0.z, vis0, p.b));
+                p.d = fma_(t.C1.w, vis1, fma_(t.C0.w, vis0, p.d));
 #ifdef SAS_TUNE_STATS
                 { const unsigned long long c3 = __popcll(__ballot(vis0 > 0.0f)) + __popcll(__ballot(vis1 > 0.0f)); DBG_ADD(3, c3); }
 #endif
                 if (__ballot(stop0) | __ballot(stop1)) {   // rare: some pixel terminated on these splats
                     if (stop0 || stop1) p.x = __builtin_nanf("");
-                    if (__all(pix_dead(p))) break;
+                    return __all(pix_dead(p));
                 }
+                return false;
+            };
+            for (int k = 0; k < kmax; k += 2) {
+                Trip t;
+                load_trip(t, k);
+                if (composite_trip(t)) break;
             }
             wdone = __all(pix_dead(p));
 #ifdef SAS_TUNE_STATS
@@ -807,7 +817,6 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 21 KiB
     __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_cur[256];   // per-bucket write cursor of the chunk being collected
     __shared__ unsigned s_wsum[4], s_wmax[4];
     __shared__ unsigned s_mn, s_mx, s_m;
     __shared__ int s_b1;
@@ -816,6 +825,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     const BlendLds L = blend_lds(s_raw);
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
+    unsigned *s_cur = dbase + 256;                                // [256] per-bucket write cursor of the chunk being collected (sort phase)
 
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();

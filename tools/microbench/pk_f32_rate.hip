@@ -47,7 +47,9 @@ template <int MODE>
 static void run(const char *name, int insts_per_iter, float *d, int clock_khz, int cus)
 {
     const int iters = 20000;
-    for (int wps = 1; wps <= 8; wps *= 2) {   // waves per SIMD: blocks of 256 threads = 1 wave per SIMD per block
+    static const int order[] = {8, 4, 2, 1, 1, 2, 4, 8};   // both directions: a clock ramp would show as asymmetry
+    for (int oi = 0; oi < 8; ++oi) {   // waves per SIMD: blocks of 256 threads = 1 wave per SIMD per block
+        const int wps = order[oi];
         const int blocks = cus * wps;
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
