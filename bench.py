@@ -42,10 +42,12 @@ from sim_a_splat_amd.synthetic import (NERFSTUDIO_EVAL_BACKGROUND as BG, config_
                                        random_group_poses, ring_camera)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Vector-instruction issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 3.0 cycles per wave-instruction, the rate a
-# SIMD sustains on independent v_fma_f32 with 4-8 waves resident (tools/microbench/pk_f32_rate.hip, measured
-# 3.0-3.35; scalar instructions go through one unit per CU and cost the same issue time)
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 3.0
+# Vector-instruction issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+# (MI355X_MICROARCH.md: v_fma_f32 2 cycles per SIMD = the 157 TFLOP/s fp32 vector peak).  Measured with
+# tools/microbench/clock_probe.hip: 1.61 shader cycles per instruction per SIMD with 8 waves resident at the
+# 1.9-1.95 GHz the chip holds under that load = 1.21e12/s, the same number; 1.98 cycles with 4 waves, and one
+# wave alone issues at most once per 6.75 cycles (profiles/r02_issue_rate_microbench.txt).
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 
 
 def scene_pass_bytes(n):
@@ -242,7 +244,7 @@ def main():
                 "bound": "vector-instruction issue", "kernel": "k_tile_lazy", "unit": "G wave-instructions/s",
                 "achieved": valu / blend_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "frac": valu / blend_s / VALU_ISSUE_PEAK,
                 "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
-                "frac_with_scalar": (valu + salu) / blend_s / VALU_ISSUE_PEAK,
+                "frac_with_scalar": (valu + salu) / blend_s / VALU_ISSUE_PEAK,   # scalar instructions take issue slots too (one scalar unit per CU)
                 "useful_frac": insts.get("composited_pixel_splats", 0) * insts.get("valu_per_composited_pixel_splat", 24) / 64 / blend_s / VALU_ISSUE_PEAK,
                 "source": "profiles/tile_insts.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, -DSAS_TUNE_STATS counters)"}
 
@@ -279,6 +281,9 @@ def main():
             for k, v in r.stage_times().items():
                 stage.setdefault(k, []).append(v)
         line["roofline"]["kernel_ms_isolated_frame"] = float(np.mean(stage["blend"]))
+        if "roofline_issue" in line:   # the same kernel with nothing else on the GPU
+            ri = line["roofline_issue"]
+            ri["frac_isolated_frame"] = ri["valu_insts_per_launch"] / (float(np.mean(stage["blend"])) * 1e-3) / VALU_ISSUE_PEAK
         line["roofline"]["isolated_frame_stage_ms"] = {k: float(np.mean(v)) for k, v in stage.items()}
     if rank == 0 and world == 1 and a.config == 3 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(scene, cams[0])

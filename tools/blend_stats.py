@@ -1,4 +1,4 @@
-"""Lane utilisation of the compositing loop (needs a -DSAS_TUNE_STATS build of the library)."""
+"""Lane utilisation of the compositing loop (needs a -DSAS_TUNE_STATS build: SAS_LIB_PATH=variants/lib_stats.so)."""
 import ctypes, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -16,9 +16,8 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     L.sas_debug_counters(out, 1)
     r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
     L.sas_debug_counters(out, 1)
-    it, itc, cand, upd, staged, queued = [int(x) for x in out[:6]]
-    wait_cyc, loop_cyc = int(out[6]), int(out[7])
+    it, _, _, upd, staged, queued = [int(x) for x in out[:6]]
+    trips = it // 2
     st = r.stats()
-    print(f"cfg{cfg}: M={st['n_isect']} staged={staged} ({staged/st['n_isect']:.2f} of M) queued pairs={queued} ({queued/max(staged,1):.2f} per staged entry)")
-    print(f"  wave cycles in the compositing loop {loop_cyc:.3g}, waiting at the batch barrier {wait_cyc:.3g} ({wait_cyc/max(loop_cyc,1):.2f} of loop)")
-    print(f"  wave-iterations={it} with candidates={itc} ({itc/max(it,1):.2f}); candidate lanes/iter={cand/max(itc,1):.1f} composited lanes/iter={upd/max(itc,1):.1f}")
+    print(f"cfg{cfg}: M={st['n_isect']} staged={staged} ({staged/st['n_isect']:.2f} of M) queued (entry, 4x4 block) pairs={queued} ({queued/max(staged,1):.2f} per staged entry)")
+    print(f"  trips={trips} (two queue entries per 16-lane group each); composited={upd} pixel-splat pairs = {upd/max(trips*128,1):.2f} of the {trips*128} lane-slots issued")
