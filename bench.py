@@ -213,7 +213,11 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         fps = views_all * a.steps / elapsed
         blend_s = max(tile_ms, 1e-9) * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
-        achieved = tile_kernel_bytes(st["n_isect"], W, H, out_bpp) / blend_s / 1e9
+        # scenes below 0.5 M Gaussians render a batch in launch groups: one tile launch covers `per_launch` views
+        per_launch = 1
+        if scene.n < 500_000 and V >= 2 and os.environ.get("SAS_GROUP", "") != "1":
+            per_launch = min(V, int(os.environ.get("SAS_GROUP", "2") or 2))
+        achieved = per_launch * tile_kernel_bytes(st["n_isect"], W, H, out_bpp) / blend_s / 1e9
         # bytes one step of THIS rank moves: one pass over the scene per view pair (config 3 with two views per
         # step: ONE pass for both), plus the per-view terms
         pair = a.config == 3 and a.views_per_step == 2 or (a.config != 3 and scene.n >= 500_000 and V >= 2)
@@ -231,7 +235,7 @@ def main():
                        "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy") if a.config == 3 else None,
-                         "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames,
+                         "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames, "views_per_kernel_launch": per_launch,
                          "step_algorithmic_bytes": step_bytes, "frame_algorithmic_GBps": step_gbps,
                          "frame_frac": step_gbps / HBM_PEAK_GBPS},
         }
