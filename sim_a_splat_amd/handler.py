@@ -99,6 +99,8 @@ class SplatHandler:
         self.weld_translation = _translation_of(weld)
         self.scale_factor, self.Ri, self.ti = poses.decompose_icp(icp_transformation)
         self.fk = [(np.asarray(T, np.float64)[:3, :3], np.asarray(T, np.float64)[:3, 3]) for T in fk_transforms]
+        self._fkR = np.stack([R for R, _ in self.fk]) if self.fk else np.zeros((0, 3, 3))
+        self._fkt = np.stack([t for _, t in self.fk]) if self.fk else np.zeros((0, 3))
         means, covs = np.asarray(means, np.float32), np.asarray(covs, np.float32)
         colors, opacities = np.asarray(colors, np.float32), np.asarray(opacities, np.float32).reshape(-1)
         self.means, self.covs, self.colors, self.opacities = means, covs, colors, opacities   # :99-102
@@ -131,22 +133,25 @@ class SplatHandler:
         return cls.from_arrays(arr(loader.means), arr(loader.covs), arr(loader.colors), arr(loader.opacities), masks, icp, fk, **kw)
 
     def draw_handler(self, msg) -> None:
-        """``msg``: lcmt_viewer_draw-shaped (num_links, robot_num[], position[][3], quaternion[][4] wxyz)."""
-        local_idx = 0
-        for idx in range(msg.num_links):
-            if msg.robot_num[idx] != self.rbt_idx:
-                continue
-            try:
-                Rfk, tfk = self.fk[local_idx]
-                R, t = poses.link_splat_pose(self.scale_factor, self.Ri, self.ti, Rfk, tfk, msg.quaternion[idx],
-                                             msg.position[idx], self.weld_translation)
-                if local_idx < 7 and local_idx < len(self.splat_links_handler):   # :282
-                    h = self.splat_links_handler[local_idx]
-                    h.wxyz = poses.matrix_to_quat_wxyz(R)
-                    h.position = t
-                local_idx += 1
-            except IndexError:
+        """``msg``: lcmt_viewer_draw-shaped (num_links, robot_num[], position[][3], quaternion[][4] wxyz).  The
+        k-th link of the robot (``robot_num == rbt_idx``, message order) drives splat group k, as in the reference
+        (:227-314); all links are posed in one batch of small matrix products."""
+        idxs = [idx for idx in range(msg.num_links) if msg.robot_num[idx] == self.rbt_idx]
+        if len(idxs) > len(self.fk):
+            for idx in idxs[len(self.fk):]:
                 logging.warning(f"Warning: Received draw command for non-existent Link index {idx}.")
+            idxs = idxs[:len(self.fk)]
+        k = min(len(idxs), 7, len(self.splat_links_handler))               # :282: at most seven link groups
+        if k == 0:
+            return
+        q = np.asarray([msg.quaternion[i] for i in idxs[:k]], dtype=np.float64)
+        p = np.asarray([msg.position[i] for i in idxs[:k]], dtype=np.float64)
+        R, t = poses.link_splat_poses(self.scale_factor, self.Ri, self.ti, self._fkR[:k], self._fkt[:k], q, p, self.weld_translation)
+        wxyz = poses.matrices_to_quats_wxyz(R)
+        for j in range(k):
+            h = self.splat_links_handler[j]
+            h.wxyz = wxyz[j]
+            h.position = t[j]
 
     def get_attached_frame(self, body_name: str, local_frame_pos, msg) -> Tuple[np.ndarray, np.ndarray]:
         """``local_frame_pos``: the camera's ``local_frame`` (SE3-like, as the reference passes it, :316-319) or

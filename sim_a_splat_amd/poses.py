@@ -13,10 +13,7 @@ import numpy as np
 
 
 def quat_wxyz_to_matrix(q: Sequence[float]) -> np.ndarray:
-    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return quats_wxyz_to_matrices(np.asarray(q, dtype=np.float64).reshape(1, 4))[0]   # one arithmetic for both forms
 
 
 def matrix_to_quat_wxyz(R: np.ndarray) -> np.ndarray:
@@ -34,7 +31,38 @@ def matrix_to_quat_wxyz(R: np.ndarray) -> np.ndarray:
         q[1 + i] = 0.25 * s
         q[1 + j] = (R[j, i] + R[i, j]) / s
         q[1 + k] = (R[k, i] + R[i, k]) / s
-    return q / np.linalg.norm(q)
+    return q / np.sqrt((q * q).sum())
+
+
+def quats_wxyz_to_matrices(q: np.ndarray) -> np.ndarray:
+    """[K,4] (any norm) -> [K,3,3]; ``quat_wxyz_to_matrix`` is this function with K = 1, so the scalar and the
+    batched form are one arithmetic."""
+    q = np.asarray(q, dtype=np.float64).reshape(-1, 4)
+    q = q / np.sqrt((q * q).sum(axis=1, keepdims=True))
+    qq = q[:, :, None] * q[:, None, :]                   # all pairwise products: qq[:, a, b] = q_a q_b (w x y z = 0 1 2 3)
+    R = np.empty((q.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (qq[:, 2, 2] + qq[:, 3, 3]); R[:, 0, 1] = 2 * (qq[:, 1, 2] - qq[:, 0, 3]); R[:, 0, 2] = 2 * (qq[:, 1, 3] + qq[:, 0, 2])
+    R[:, 1, 0] = 2 * (qq[:, 1, 2] + qq[:, 0, 3]); R[:, 1, 1] = 1 - 2 * (qq[:, 1, 1] + qq[:, 3, 3]); R[:, 1, 2] = 2 * (qq[:, 2, 3] - qq[:, 0, 1])
+    R[:, 2, 0] = 2 * (qq[:, 1, 3] - qq[:, 0, 2]); R[:, 2, 1] = 2 * (qq[:, 2, 3] + qq[:, 0, 1]); R[:, 2, 2] = 1 - 2 * (qq[:, 1, 1] + qq[:, 2, 2])
+    return R
+
+
+def matrices_to_quats_wxyz(R: np.ndarray) -> np.ndarray:
+    """[K,3,3] -> [K,4] unit quaternions; the branches of ``matrix_to_quat_wxyz`` (trace > 0, else the largest
+    diagonal element), evaluated for all K at once."""
+    R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+    K = R.shape[0]
+    q = np.empty((K, 4))
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    pos = tr > 0
+    if pos.any():
+        Rp = R[pos]
+        s = np.sqrt(tr[pos] + 1.0) * 2
+        qp = np.stack([0.25 * s, (Rp[:, 2, 1] - Rp[:, 1, 2]) / s, (Rp[:, 0, 2] - Rp[:, 2, 0]) / s, (Rp[:, 1, 0] - Rp[:, 0, 1]) / s], axis=1)
+        q[pos] = qp / np.sqrt((qp * qp).sum(axis=1, keepdims=True))
+    for k in np.nonzero(~pos)[0]:
+        q[k] = matrix_to_quat_wxyz(R[k])          # already normalised
+    return q
 
 
 class SO3:
@@ -123,6 +151,19 @@ def link_splat_pose(scale: float, Ri: np.ndarray, ti: np.ndarray, Rfk: np.ndarra
     msg = Sim3(1.0, quat_wxyz_to_matrix(q_msg), np.asarray(p_msg, np.float64) + np.asarray(weld_t, np.float64))
     g = icp @ msg @ fk.inv() @ icp.inv()
     return g.R, g.t
+
+
+def link_splat_poses(scale: float, Ri: np.ndarray, ti: np.ndarray, Rfk: np.ndarray, tfk: np.ndarray, q_msg: np.ndarray,
+                     p_msg: np.ndarray, weld_t=(0.0, 0.0, 0.0)) -> Tuple[np.ndarray, np.ndarray]:
+    """``link_splat_pose`` for K links at once (Rfk [K,3,3], tfk [K,3], q_msg [K,4], p_msg [K,3]) in the
+    reference's expanded form (splat_handler.py:265-278):
+        R = Ri Rm Rfk^T Ri^T,   t = ti - R ti + s Ri (tm - Rm Rfk^T tfk),   tm = p_msg + weld."""
+    Rm = quats_wxyz_to_matrices(q_msg)
+    tm = np.asarray(p_msg, np.float64).reshape(-1, 3) + np.asarray(weld_t, np.float64)
+    RmF = Rm @ np.transpose(np.asarray(Rfk, np.float64), (0, 2, 1))            # Rm Rfk^T
+    R = Ri @ RmF @ Ri.T
+    t = ti - R @ ti + scale * (tm - np.einsum("kij,kj->ki", RmF, np.asarray(tfk, np.float64))) @ Ri.T
+    return R, t
 
 
 def attached_frame(scale: float, Ri: np.ndarray, ti: np.ndarray, q_link: Sequence[float], p_link: Sequence[float],

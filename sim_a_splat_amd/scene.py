@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .poses import quat_wxyz_to_matrix, rt_to_row12
+from .poses import quat_wxyz_to_matrix, quats_wxyz_to_matrices
 from .rasterizer import Rasterizer
 
 DEFAULT_VERTICAL_FOV = float(np.deg2rad(75.0))   # the reference never passes a FOV; viser uses the client's
@@ -96,8 +96,10 @@ class SplatScene:
             self._uploaded = True
             self._poses_dirty = True
         if self._poses_dirty and self._groups:
-            Rt = np.stack([rt_to_row12(quat_wxyz_to_matrix(h.wxyz), h.position) for h in self._handles])
-            self._raster.set_group_poses(Rt)
+            Rt = np.empty((len(self._handles), 3, 4), dtype=np.float32)
+            Rt[:, :, :3] = quats_wxyz_to_matrices(np.stack([h.wxyz for h in self._handles]))
+            Rt[:, :, 3] = np.stack([h.position for h in self._handles])
+            self._raster.set_group_poses(Rt.reshape(-1, 12))
         self._poses_dirty = False
 
     @staticmethod
@@ -109,6 +111,20 @@ class SplatScene:
         f = 0.5 * height / np.tan(0.5 * fov)               # vertical FOV, square pixels
         K = np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]])
         return V.astype(np.float32), K.astype(np.float32)
+
+    @staticmethod
+    def _views_and_Ks(height: int, width: int, wxyz: np.ndarray, position: np.ndarray, fov: float):
+        """``_view_and_K`` for C cameras at once: ([C,4,4], [C,3,3]) float32, the same arithmetic per camera."""
+        R = quats_wxyz_to_matrices(wxyz)
+        C = R.shape[0]
+        V = np.zeros((C, 4, 4))
+        Rt = np.transpose(R, (0, 2, 1))
+        V[:, :3, :3] = Rt
+        V[:, :3, 3] = -np.stack([Rt[c] @ np.asarray(position[c], dtype=np.float64) for c in range(C)])
+        V[:, 3, 3] = 1.0
+        f = 0.5 * height / np.tan(0.5 * fov)
+        K = np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]])
+        return V.astype(np.float32), np.broadcast_to(K.astype(np.float32), (C, 3, 3)).copy()
 
     # -- client side ---------------------------------------------------------------------------
     def get_render(self, height: int, width: int, wxyz=None, position=None, fov: Optional[float] = None) -> np.ndarray:
@@ -124,9 +140,9 @@ class SplatScene:
         """uint8 [C,H,W,3] for C same-sized cameras ``[(wxyz, position), ...]`` in one batched call."""
         self._sync()
         f = self.camera.fov if fov is None else float(fov)
-        VK = [self._view_and_K(int(height), int(width), w, p, f) for (w, p) in cam_poses]
-        out = self._raster.render_batch(np.stack([v for v, _ in VK]), np.stack([k for _, k in VK]), int(width), int(height),
-                                        self.background, want=("rgb8",))
+        Vs, Ks = self._views_and_Ks(int(height), int(width), np.stack([np.asarray(w, dtype=np.float64) for w, _ in cam_poses]),
+                                    [p for _, p in cam_poses], f)
+        out = self._raster.render_batch(Vs, Ks, int(width), int(height), self.background, want=("rgb8",))
         return out["rgb8"].cpu().numpy()
 
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
