@@ -802,7 +802,33 @@ constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per r
 #define SAS_TUNE_RANKMAX 32
 #endif
 constexpr int kRankMax = SAS_TUNE_RANKMAX;   // largest depth bucket a chunk is ordered by counting (else radix passes)
+#ifndef SAS_TUNE_PARTMIN
+#define SAS_TUNE_PARTMIN (8 * SAS_TUNE_CHUNK)
+#endif
+// A list that still holds more than this many keys when its SECOND round starts is laid out by bucket once
+// (later rounds then read only their own chunk); shorter remainders are cheaper to re-scan (measured: the
+// layout pass + the per-chunk depth gathers cost 3 % at config 2, lists of ~4 000).
+constexpr int kPartitionMin = SAS_TUNE_PARTMIN;
 constexpr int kLazyThreads = 256;
+
+// Lay the keys of buckets >= b_first out by bucket: slot ids into `ids` at the positions handed out by the
+// per-bucket cursors `cur` (LDS, preset to each bucket's start).  A real call, not inlined: it runs once for
+// the rare tile that needs many rounds, and inlining it costs the common path registers (+1 % at configs 2, 3).
+__device__ __attribute__((noinline)) void partition_by_bucket(const unsigned long long *g, int n, unsigned dmin, int shift, int b_first,
+                                                              unsigned *cur, int *ids)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += kLazyThreads) {
+        const unsigned long long key = g[i];
+        const int b = (int)((hi32(key) - dmin) >> shift);
+        if (b >= b_first && SAS_IN(b, 256, 214)) {
+            const unsigned pos = atomicAdd(&cur[b], 1u);
+            if (SAS_IN(pos, n, 215)) ids[pos] = (int)lo32(key);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
 
 template <bool FAST_EXP, bool WANT_MAX>
 DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm)
@@ -826,6 +852,8 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
     unsigned *s_cur = dbase + 256;                                // [256] per-bucket write cursor of the chunk being collected (sort phase)
+    __shared__ unsigned s_pstart[256];                            // start of every remaining bucket in the bucket-ordered id segment
+    __shared__ unsigned s_rem;
 
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();
@@ -913,6 +941,8 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         __syncthreads();
         int b_next = 0;
         bool bail = false;
+        bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
+        int *const ids = f.sorted_ids + beg;      // ... as storage slots in the tile's (otherwise unused) id segment
         for (;;) {
             // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
             //      whose running count from b0 stays <= kChunk.  Thread t owns bucket t.
@@ -930,6 +960,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 for (int w = 0; w < wv; ++w) incl += s_wsum[w];        // inclusive count of buckets b_next..tid
                 my_hv = hv;
                 my_incl = incl;
+                if (tid == kLazyThreads - 1) s_rem = incl;             // keys not yet consumed (buckets >= b_next)
                 const unsigned long long nz = __ballot(hv != 0u);
                 const unsigned long long fit = __ballot(hv != 0u && incl <= (unsigned)kChunk);
                 if (lane == 0) {
@@ -954,29 +985,56 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             __syncthreads();
             if (b1 == 256) break;                 // nothing left
             if (b1 < 0) { bail = true; break; }   // one bucket larger than the chunk: full path
+            // ---- a SECOND round starts (the first chunk did not saturate the tile, which is the exception):
+            //      lay the remaining keys out by bucket, once, so that every later round reads only its own
+            //      chunk instead of scanning the whole list again (n^2 / 512 key reads on a long translucent list;
+            //      only worth it when many rounds are still to come: kPartitionMin).
+            //      Bucket t of the remainder starts at the exclusive count of buckets b_next .. t - 1: the scan above.
+            if (!partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
+                s_pstart[tid] = my_incl - my_hv;
+                s_cur[tid] = my_incl - my_hv;
+                __syncthreads();
+                partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
+                partitioned = true;
+            }
             // ---- collect the range into LDS grouped by bucket (bucket t starts at the exclusive count of
             //      the buckets before it), depth words relative to the range's base
             const unsigned base = dmin + ((unsigned)b0 << shift);
             const bool mine = tid >= b0 && tid <= b1;
-            if (mine) s_cur[tid] = my_incl - my_hv;
             if (tid == b1) s_m = my_incl;                            // entries in the chunk
+            if (!partitioned) {
+                if (mine) s_cur[tid] = my_incl - my_hv;
+            } else if (mine) {
+                s_cur[tid] = s_pstart[tid] + my_hv - s_pstart[b0];   // END of bucket t inside the chunk (what the collect pass leaves)
+            }
             const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
-            for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
-                unsigned long long kk[U];
+            if (!partitioned) {
+                for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+                    unsigned long long kk[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * kLazyThreads + tid;
-                    kk[u] = (i < n) ? g[i] : ~0ull;
-                }
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * kLazyThreads + tid;
+                        kk[u] = (i < n) ? g[i] : ~0ull;
+                    }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (i0 + u * kLazyThreads + tid < n) {
-                        const int b = (int)((hi32(kk[u]) - dmin) >> shift);
-                        if (b >= b0 && b <= b1 && SAS_IN(b, 256, 206)) {
-                            const unsigned pos = atomicAdd(&s_cur[b], 1u);
-                            if (SAS_IN(pos, kChunk, 207)) ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                    for (int u = 0; u < U; ++u) {
+                        if (i0 + u * kLazyThreads + tid < n) {
+                            const int b = (int)((hi32(kk[u]) - dmin) >> shift);
+                            if (b >= b0 && b <= b1 && SAS_IN(b, 256, 206)) {
+                                const unsigned pos = atomicAdd(&s_cur[b], 1u);
+                                if (SAS_IN(pos, kChunk, 207)) ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                            }
                         }
                     }
+                }
+            } else {
+                // the chunk is one contiguous run of the bucket-ordered slots; depth words come from the projection's info
+                const int st = (int)s_pstart[b0], cnt_chunk = (int)s_m;
+                for (int i = tid; i < cnt_chunk; i += kLazyThreads) {
+                    if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, kChunk, 217)) continue;
+                    const unsigned slot = (unsigned)ids[st + i];
+                    const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? f.info[slot].z : dmin;
+                    ck[i] = ((unsigned long long)(dbits - base) << 32) | slot;
                 }
             }
             __syncthreads();
