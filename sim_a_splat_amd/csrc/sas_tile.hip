@@ -493,16 +493,18 @@ extern "C" int sas_debug_wg(unsigned long long *out, int n)
 }
 #endif
 #ifdef SAS_TUNE_STATS
-// A/B builds only: [0] wave-iterations of the compositing loop, [1] of those with a candidate lane,
-// [2] candidate lanes, [3] lanes that composited, [4] staged entries, [5] queued (entry, block) pairs,
-// [6] / [7] wave cycles waiting at the batch barrier / inside the compositing loop
-__device__ unsigned long long g_dbg[8];
+// A/B builds only: [0] wave-iterations of the compositing loop, [1] trips on which a pixel terminated,
+// [2] pixels that terminated, [3] lanes that composited, [4] staged entries, [5] queued (entry, block) pairs,
+// [6] / [7] wave cycles waiting at the batch barrier / inside the compositing loop,
+// [8] (entry, 16-lane group) slots in which at least one lane composited, [9] slots that held the sentinel,
+// [10] slots of a group whose 16 pixels had all terminated (after the trip), [11] slots of a live group in which no lane passed the alpha test (includes sentinels)
+__device__ unsigned long long g_dbg[12];
 extern "C" int sas_debug_counters(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
 
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -561,10 +563,12 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         }
     };
     if (count > 0) fetch(0);
-    if (tid == 0) {   // sentinel record: sigma = 0 against threshold -1
-        L.q0[256] = make_float4(0, 0, 0, 0);
-        L.q1[256] = make_float4(0, 0, -1.0f, 0);
-        L.q2[256] = make_float4(0, 0, 0, 0);
+    if (tid == 0) {   // sentinel record: opacity 0 (built here from opaque registers: hipcc otherwise keeps the
+        // constant vectors alive across the tile's rounds and spills them)
+        const float z0 = vgpr_const(0u), m1 = vgpr_const(0xbf800000u);
+        L.q0[256] = make_float4(z0, z0, z0, z0);
+        L.q1[256] = make_float4(z0, z0, m1, z0);
+        L.q2[256] = make_float4(z0, z0, z0, z0);
     }
     const float X0 = (float)(tx * SAS_TILE), Y0 = (float)(ty * SAS_TILE);
     // this lane's block: bit in the entry masks, and its queue
@@ -607,7 +611,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         }
         if (!wdone) {   // all four queues of the wave start as sentinels (2 KiB: 32 bytes per lane)
             uint4 *z = reinterpret_cast<uint4 *>(wq) + 2 * lane;
-            const unsigned sw = (256u << 4) | ((256u << 4) << 16);
+            // (materialised here: hipcc otherwise keeps the four registers of the constant alive across the
+            // whole tile and spills them to scratch, one 16-byte reload per batch)
+            const unsigned sw = __float_as_uint(vgpr_const((256u << 4) | ((256u << 4) << 16)));
             z[0] = make_uint4(sw, sw, sw, sw);
             z[1] = make_uint4(sw, sw, sw, sw);
         }
@@ -616,6 +622,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         if (!wdone) {
             const int cnt = (count - at) < 256 ? (count - at) : 256;
             int qn[4] = {0, 0, 0, 0};
+            // 16 * lane, opaque to the optimiser: it otherwise hoists the four queue values 16 (64 j + lane) out
+            // of the batch loop and spills them (16 scratch reloads per batch, each with a full vmcnt wait)
+            unsigned lane16 = (unsigned)lane << 4;
+            asm volatile("" : "+v"(lane16));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (64 * j >= cnt) break;   // partial batch (uniform)
@@ -627,9 +637,17 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                     const bool has = (me >> bit) & 1u;
                     const unsigned long long m = __ballot(has);
                     if (has && SAS_IN(qn[g] + (int)__popcll(m & lt_mask), 256, 202))
-                        wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(e << 4);
+                        wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(lane16 + 1024u * j);
                     qn[g] += (int)__popcll(m);
                 }
+            }
+            // a 4x4 block whose 16 pixels have all terminated does not prolong the walk (13 % of the queue slots
+            // walked at config 3 belonged to such blocks; a trip lasts as long as the wave's longest queue)
+            {
+                const unsigned long long dm = __ballot(pix_dead(p));
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (((dm >> (16 * g)) & 0xffffull) == 0xffffull) qn[g] = 0;
             }
             const int kmax = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
 #ifdef SAS_TUNE_STATS
@@ -643,6 +661,12 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             struct Trip { float4 K0, H0, K1, H1, C0, C1; };
             auto load_trip = [&](Trip &t, int k, unsigned pair) {   // pair = queue entries k, k + 1
                 unsigned off0 = pair & 0xffffu, off1 = pair >> 16;
+#ifdef SAS_TUNE_STATS
+                {
+                    const unsigned long long e0 = __ballot(off0 == (256u << 4)), e1 = __ballot(off1 == (256u << 4));
+                    DBG_ADD(9, (__popcll(e0) + __popcll(e1)) / 16);
+                }
+#endif
                 if (!SAS_IN(k + 1, 256, 203) || !SAS_IN(off0 >> 4, kStage, 204) || !SAS_IN(off1 >> 4, kStage, 205)) off0 = off1 = 256u << 4;
                 t.K0 = *reinterpret_cast<const float4 *>(q0b + off0);
                 t.H0 = *reinterpret_cast<const float4 *>(q1b + off0);
@@ -666,33 +690,52 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 else { E0 = c_expf_neg(fmaxf(-sg0, -86.0f), sE5); E1 = c_expf_neg(fmaxf(-sg1, -86.0f), sE5); }
                 const float al0 = fminf(kMaxAlpha, t.H0.w * E0);
                 const float al1 = fminf(kMaxAlpha, t.H1.w * E1);
-                // first entry: weight w = alpha T (0 when skipped), next T = T - w
+                // weight w = alpha T (0 when the splat is skipped), next T = T - w, for both entries as if no
+                // pixel terminated; T only falls, so one test of the last T tells whether any did
                 const float w0 = (al0 < kAlphaThr) ? 0.0f : al0 * p.T;
                 const float nT0 = p.T - w0;
-                const bool stop0 = nT0 <= kTStop;   // the splat that ends a pixel is not added (a live pixel has T > 1e-4, so a skipped splat never stops it)
+                const float w1 = (al1 < kAlphaThr) ? 0.0f : al1 * nT0;
+                const float nT1 = nT0 - w1;
+                float vis0 = w0, vis1 = w1, Tn = nT1;
+                bool all_dead = false;
+                if (__ballot(nT1 <= kTStop)) {   // 31 % of the trips at configs 2 and 3
+                    // the splat that ends a pixel is not added, and the pixel takes nothing after it
+                    // (a live pixel has T > 1e-4, so a skipped splat never stops it)
+                    const bool stop0 = nT0 <= kTStop, stopped = nT1 <= kTStop;
+                    vis0 = stop0 ? 0.0f : w0;
+                    vis1 = stopped ? 0.0f : w1;
+                    Tn = stop0 ? p.T : (stopped ? nT0 : nT1);
+                    if (stopped) p.x = __builtin_nanf("");
+                    all_dead = __all(pix_dead(p));
+                }
+                p.T = Tn;
                 // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
-                // colours and depths of the path, so one select on the weight replaces four
-                const float vis0 = stop0 ? 0.0f : w0;
-                const float Tm = stop0 ? p.T : nT0;
-                // second entry: a pixel the first one terminated takes nothing more
-                const float a1 = stop0 ? 0.0f : al1;
-                const float w1 = (a1 < kAlphaThr) ? 0.0f : a1 * Tm;
-                const float nT1 = Tm - w1;
-                const bool stop1 = nT1 <= kTStop;
-                const float vis1 = stop1 ? 0.0f : w1;
-                p.T = stop1 ? Tm : nT1;
+                // colours and depths of the path
                 p.r = fma_(t.C1.x, vis1, fma_(t.C0.x, vis0, p.r));
                 p.g = fma_(t.C1.y, vis1, fma_(t.C0.y, vis0, p.g));
                 p.b = fma_(t.C1.z, vis1, fma_(t.C0.z, vis0, p.b));
                 p.d = fma_(t.C1.w, vis1, fma_(t.C0.w, vis0, p.d));
 #ifdef SAS_TUNE_STATS
-                { const unsigned long long c3 = __popcll(__ballot(vis0 > 0.0f)) + __popcll(__ballot(vis1 > 0.0f)); DBG_ADD(3, c3); }
-#endif
-                if (__ballot(stop0) | __ballot(stop1)) {   // rare: some pixel terminated on these splats
-                    if (stop0 || stop1) p.x = __builtin_nanf("");
-                    return __all(pix_dead(p));
+                {
+                    const unsigned long long m0 = __ballot(vis0 > 0.0f), m1 = __ballot(vis1 > 0.0f);
+                    const unsigned long long a0 = __ballot(al0 >= kAlphaThr), a1m = __ballot(al1 >= kAlphaThr);
+                    const unsigned long long dm = __ballot(pix_dead(p)), sb = __ballot(nT1 <= kTStop);
+                    int used = 0, gdead = 0, nopass = 0;
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const bool dead = ((dm >> (16 * gq)) & 0xffffull) == 0xffffull;
+                        used += (int)(((m0 >> (16 * gq)) & 0xffffull) != 0) + (int)(((m1 >> (16 * gq)) & 0xffffull) != 0);
+                        gdead += dead ? 2 : 0;
+                        if (!dead) nopass += (int)(((a0 >> (16 * gq)) & 0xffffull) == 0) + (int)(((a1m >> (16 * gq)) & 0xffffull) == 0);
+                    }
+                    DBG_ADD(3, __popcll(m0) + __popcll(m1));
+                    DBG_ADD(8, used);
+                    DBG_ADD(10, gdead);
+                    DBG_ADD(11, nopass);
+                    DBG_ADD(1, sb != 0);
+                    DBG_ADD(2, __popcll(sb));
                 }
-                return false;
+#endif
+                return all_dead;
             };
             // One exit: the trip counter lives on the scalar unit, and a wave whose pixels have all terminated
             // jumps it to the end (a `break` makes hipcc merge two exits through lane masks: six more

@@ -11,13 +11,18 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     r = Rasterizer(0)
     r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
     L = _capi.lib()
-    out = (ctypes.c_uint64 * 8)()
+    out = (ctypes.c_uint64 * 12)()
     r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
     L.sas_debug_counters(out, 1)
     r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
     L.sas_debug_counters(out, 1)
-    it, _, _, upd, staged, queued = [int(x) for x in out[:6]]
+    it, stop_trips, stops, upd, staged, queued = [int(x) for x in out[:6]]
     trips = it // 2
     st = r.stats()
     print(f"cfg{cfg}: M={st['n_isect']} staged={staged} ({staged/st['n_isect']:.2f} of M) queued (entry, 4x4 block) pairs={queued} ({queued/max(staged,1):.2f} per staged entry)")
     print(f"  trips={trips} (two queue entries per 16-lane group each); composited={upd} pixel-splat pairs = {upd/max(trips*128,1):.2f} of the {trips*128} lane-slots issued")
+    print(f"  trips on which a pixel terminated: {stop_trips} ({stop_trips/max(trips,1):.2f} of the trips), {stops} pixels")
+    used, sentinel = int(out[8]), int(out[9])
+    print(f"  (entry, 16-lane group) slots: {trips*8} issued, {sentinel} sentinels ({sentinel/max(trips*8,1):.2f}), {used} with a compositing lane ({used/max(trips*8,1):.2f})")
+    gdead, nopass = int(out[10]), int(out[11])
+    print(f"  slots of a group that had entirely terminated: {gdead} ({gdead/max(trips*8,1):.2f}); slots of a live group without a lane passing the alpha test, sentinels included: {nopass} ({nopass/max(trips*8,1):.2f})")
