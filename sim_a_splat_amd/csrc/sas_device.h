@@ -12,6 +12,9 @@ constexpr float kNear = 0.01f, kFar = 1e10f, kEps2d = 0.3f;
 constexpr float kAlphaThr = 1.0f / 255.0f, kMaxAlpha = 0.999f, kTStop = 1e-4f;
 
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// set bits of m below this lane's position (v_mbcnt_lo/hi: two instructions; hipcc does not form them from
+// __popcll(m & lanes_below))
+DEV unsigned mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
 // ---- bounds-checked build (-DSAS_DEBUG_BOUNDS; GPU AddressSanitizer is not available on this pool) ----------
 // SAS_IN(i, n, code) is `true` in the product build.  In the debug build it tests 0 <= i < n; a violation

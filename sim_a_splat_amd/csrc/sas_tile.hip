@@ -53,7 +53,6 @@ DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nbu = (((m + W - 1) / W) + 63) >> 6;   // 64-key batches per wave, <= NB
     const int base = wv * (nbu * 64) + lane;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long k[NB];
     for (int byte = 0; byte < 4; ++byte) {
         if ((span >> (8 * byte)) == 0u) break;   // uniform
@@ -76,7 +75,7 @@ DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int
                 const unsigned long long bm = __ballot(on);
                 mm &= on ? bm : ~bm;
             }
-            const unsigned below = (unsigned)__popcll(mm & lt_mask);
+            const unsigned below = mbcnt64(mm);
             const unsigned total = (unsigned)__popcll(mm);
             const unsigned prev = act ? cnt[wv * 256 + d] : 0u;
             if (act && below == 0u) cnt[wv * 256 + d] = prev + total;
@@ -280,7 +279,6 @@ __global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *perm, c
     __shared__ unsigned short si[CAP];
     __shared__ __attribute__((aligned(16))) unsigned cnt[256];
     const int lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
         const int t = tl[oi];
         const long long beg = f.tile_offset[t];
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *perm, c
                     const unsigned long long bm = __ballot(on);
                     m &= on ? bm : ~bm;
                 }
-                const unsigned below = (unsigned)__popcll(m & lt_mask);
+                const unsigned below = mbcnt64(m);
                 const unsigned total = (unsigned)__popcll(m);
                 const unsigned prev = act ? cnt[d] : 0u;
                 if (act && below == 0u) cnt[d] = prev + total;
@@ -405,7 +403,9 @@ __global__ __launch_bounds__(64) void k_sort_wave(SasFrame f, const int *perm, c
 DEV unsigned block_mask16(int tx, int ty, float mx, float my, float A, float B, float C, float thr)
 {
     const float r2 = 1.125f * (A + C) + 2.25f * fabsf(B);
-    const float lim = sqrtf(thr + 0.05f) + sqrtf(r2);
+    // hardware square roots (1 ulp, no IEEE fix-up): the limit only feeds this conservative test, whose 0.05
+    // margin is five orders of magnitude above their error (the IEEE forms cost 30 instructions per entry)
+    const float lim = __builtin_amdgcn_sqrtf(thr + 0.05f) + __builtin_amdgcn_sqrtf(r2);
     const float lim2 = lim * lim;
     float hx[4], bx[4], hy[4], dy[4];
 #pragma unroll
@@ -546,7 +546,6 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                      const BlendLds &L, PixState &p, bool &wdone)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     bool have = false;
     const float sE5 = vgpr_const(0x3aafa464u);   // leading exp coefficient
@@ -636,8 +635,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                     const int bit = ((wv & 1) * 2 + (g & 1)) + 4 * ((wv >> 1) * 2 + (g >> 1));
                     const bool has = (me >> bit) & 1u;
                     const unsigned long long m = __ballot(has);
-                    if (has && SAS_IN(qn[g] + (int)__popcll(m & lt_mask), 256, 202))
-                        wq[g * 256 + qn[g] + (int)__popcll(m & lt_mask)] = (unsigned short)(lane16 + 1024u * j);
+                    const int below = (int)mbcnt64(m);
+                    if (has && SAS_IN(qn[g] + below, 256, 202)) wq[g * 256 + qn[g] + below] = (unsigned short)(lane16 + 1024u * j);
                     qn[g] += (int)__popcll(m);
                 }
             }
