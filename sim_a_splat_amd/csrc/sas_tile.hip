@@ -935,6 +935,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         // ---- short list: one pass, keys loaded once into registers, whole list is the chunk
         constexpr int NK = kChunk / kLazyThreads;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
+        s_hist[tid] = 0u;
         __syncthreads();
         unsigned long long kk[NK];
         unsigned mn = ~0u, mx = 0u;
@@ -949,6 +950,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
         const unsigned dmin = s_mn, span = s_mx - s_mn;
+#ifdef SAS_TUNE_SHORT_RADIX
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
             const int i = u * kLazyThreads + tid;
@@ -956,6 +958,46 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         }
         __syncthreads();
         if (!(ablate & 1)) lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
+#else
+        // Ordered as a chunk of a long list is: 256 depth buckets over the list's range, keys placed grouped by
+        // bucket, every key ranked inside its own bucket (a handful of compares) -- a third of the instructions
+        // of three radix passes.  A crowded bucket (coplanar splats) falls back to the radix passes.
+        const int sbits = span ? 32 - __clz(span) : 0;
+        const int shift = sbits > 8 ? sbits - 8 : 0;
+#pragma unroll
+        for (int u = 0; u < NK; ++u)
+            if (u * kLazyThreads + tid < n && SAS_IN((hi32(kk[u]) - dmin) >> shift, 256, 219)) atomicAdd(&s_hist[(hi32(kk[u]) - dmin) >> shift], 1u);
+        __syncthreads();
+        {
+            const unsigned hv = s_hist[tid];
+            unsigned incl = hv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            for (int w = 0; w < wv; ++w) incl += s_wsum[w];
+            s_cur[tid] = incl - hv;   // start of bucket tid
+            const bool big = __syncthreads_or(hv > (unsigned)kRankMax);
+#pragma unroll
+            for (int u = 0; u < NK; ++u) {
+                if (u * kLazyThreads + tid < n) {
+                    const unsigned rel = hi32(kk[u]) - dmin;
+                    if (SAS_IN(rel >> shift, 256, 220)) {
+                        const unsigned pos = atomicAdd(&s_cur[rel >> shift], 1u);   // leaves the END of every bucket
+                        if (SAS_IN(pos, kChunk, 221)) ck[pos] = ((unsigned long long)rel << 32) | lo32(kk[u]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (!(ablate & 1)) {
+                if (!big) lds_bucket_rank_sort<NK>(ck, n, 0, shift, s_hist, s_cur, perm);
+                else lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
+            }
+        }
+#endif
         if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
     } else if (n > kChunk) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
