@@ -907,7 +907,6 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
     unsigned *s_cur = dbase + 256;                                // [256] per-bucket write cursor of the chunk being collected (sort phase)
-    __shared__ unsigned s_pstart[256];                            // start of every remaining bucket in the bucket-ordered id segment
     __shared__ unsigned s_rem;
 
 #ifdef SAS_TUNE_WGTIME
@@ -1039,6 +1038,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         int b_next = 0;
         bool bail = false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
+        int p_consumed = 0;                       // ... and this many of them have been composited since
         int *const ids = f.sorted_ids + beg;      // ... as storage slots in the tile's (otherwise unused) id segment
         for (;;) {
             // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
@@ -1088,7 +1088,6 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             //      only worth it when many rounds are still to come: kPartitionMin).
             //      Bucket t of the remainder starts at the exclusive count of buckets b_next .. t - 1: the scan above.
             if (!partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
-                s_pstart[tid] = my_incl - my_hv;
                 s_cur[tid] = my_incl - my_hv;
                 __syncthreads();
                 partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
@@ -1102,7 +1101,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             if (!partitioned) {
                 if (mine) s_cur[tid] = my_incl - my_hv;
             } else if (mine) {
-                s_cur[tid] = s_pstart[tid] + my_hv - s_pstart[b0];   // END of bucket t inside the chunk (what the collect pass leaves)
+                s_cur[tid] = my_incl;   // END of bucket t inside the chunk (what the collect pass leaves): b0 is the first non-empty bucket of the scan
             }
             const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
             if (!partitioned) {
@@ -1126,7 +1125,8 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 }
             } else {
                 // the chunk is one contiguous run of the bucket-ordered slots; depth words come from the projection's info
-                const int st = (int)s_pstart[b0], cnt_chunk = (int)s_m;
+                // buckets are consumed whole and in order, so the chunk starts where the previous ones ended
+                const int st = p_consumed, cnt_chunk = (int)s_m;
                 for (int i = tid; i < cnt_chunk; i += kLazyThreads) {
                     if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, kChunk, 217)) continue;
                     const unsigned slot = (unsigned)ids[st + i];
@@ -1151,6 +1151,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, m,
                                                  [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
             if (all_done) break;
+            if (partitioned) p_consumed += m;
             b_next = b1 + 1;
             if (b_next > 255) break;
         }

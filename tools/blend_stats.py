@@ -26,3 +26,5 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     print(f"  (entry, 16-lane group) slots: {trips*8} issued, {sentinel} sentinels ({sentinel/max(trips*8,1):.2f}), {used} with a compositing lane ({used/max(trips*8,1):.2f})")
     gdead, nopass = int(out[10]), int(out[11])
     print(f"  slots of a group that had entirely terminated: {gdead} ({gdead/max(trips*8,1):.2f}); slots of a live group without a lane passing the alpha test, sentinels included: {nopass} ({nopass/max(trips*8,1):.2f})")
+    wait_c, loop_c = int(out[6]), int(out[7])
+    print(f"  wave cycles inside the trips {loop_c/1e6:.1f} M, waiting at the batch barrier for the slowest wave {wait_c/1e6:.1f} M ({wait_c/max(loop_c,1):.2f} of the trip time)")
