@@ -97,6 +97,10 @@ struct sas_ctx {
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
+    // quad layout of the tile kernel (four workgroups per tile): -1 = for launches of at most quad_max_tiles
+    // tiles (all views of a launch group counted), 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
+    int quad_mode = -1;
+    int quad_max_tiles = 640;
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
     // cameras) in groups that share one set of launches (grid.y = view).  SAS_GROUP=1 disables, 2..4 sets the size.
     int group_views = -1;           // -1: half of the slots (two groups can be in flight)
@@ -256,6 +260,13 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
 // for it and continues with its own binning and tiles.
 enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 
+// quad layout for a launch of `launch_tiles` tiles in all?
+bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags)
+{
+    if ((flags & SAS_FULL_SORT) || !sas_tiles_lazy_quad_ok((flags & SAS_FAST_EXP) != 0)) return false;
+    return c->quad_mode < 0 ? launch_tiles <= c->quad_max_tiles : c->quad_mode != 0;
+}
+
 size_t counter_bytes(int tiles)
 {
     const size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
@@ -322,12 +333,13 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role, Sl
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
+    const bool quad = !full && use_quad(c, tiles, a.flags);
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
-    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill,
+    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill, quad,
                                ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
     const bool pts = a.depth && (a.points || a.mask);
-    if (fill || pts) sas_launch_depth_tail(st, tiles, P, f, fill, pts);
+    if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
     HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -356,7 +368,7 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(4 * tiles + 16)))) return rc;
     if ((rc = ensure(c, q.counters, counter_bytes(tiles)))) return rc;
     if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
-    if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
+    if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * 4 * (size_t)tiles))) return rc;   // x 4: one slot per quadrant in the quad layout
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, sl.params_dev, sizeof(SasParams)))) return rc;
@@ -439,13 +451,14 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
-    sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill,
+    const bool quad = use_quad(c, tiles * n, a.flags);
+    sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill, quad,
                                 ttiles ? ld.ev[4] : nullptr, ttiles ? ld.ev[5] : nullptr);
     for (int k = 0; k < n; ++k) {
         const RenderArgs &ak = sl[k]->args;
         const bool fill = ak.depth && (ak.flags & SAS_DEPTH_FILL_MAX);
         const bool pts = ak.depth && (ak.points || ak.mask);
-        if (fill || pts) sas_launch_depth_tail(st, tiles, mf.P[k], mf.f[k], fill, pts);
+        if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, mf.P[k], mf.f[k], fill, pts);
     }
     HIP_TRY(c, hipEventRecord(ld.gpu_done, st));
     for (int k = 0; k < n; ++k)
@@ -565,6 +578,11 @@ int sas_create(int device, sas_ctx **out)
     if (const char *e = getenv("SAS_GROUP")) {
         const int v = atoi(e);
         if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
+    }
+    if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("SAS_QUAD_TILES")) {
+        const int v = atoi(e);
+        if (v >= 0) c->quad_max_tiles = v;
     }
     ok = ok && hipHostMalloc((void **)&c->groups_pinned, sizeof(float) * 12 * 256) == hipSuccess;
     for (Slot &sl : c->slots) {

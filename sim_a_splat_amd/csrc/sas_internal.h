@@ -54,7 +54,7 @@ struct SasFrame {
     long long cap;
     unsigned *stats;           // [8]
     int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup
-    unsigned *tile_max;        // [tiles] per-tile max expected depth (bits), written when depth is filled
+    unsigned *tile_max;        // [4 * tiles] per-tile (quad layout: per-quadrant) max expected depth (bits), written when depth is filled
     int n_wg;
     int n_tiles;               // tw * th
 };
@@ -103,7 +103,7 @@ void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti 
 void sas_launch_scan_multi(hipStream_t st, int tiles, const SasMulti &mf);
 void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf);
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
-                                 hipEvent_t ev_start, hipEvent_t ev_stop);
+                                 bool quad, hipEvent_t ev_start, hipEvent_t ev_stop);
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f);
 struct SasSortStreams {
     hipStream_t side[2];   // nullptr: run the classes back to back on the frame's stream
@@ -112,8 +112,11 @@ struct SasSortStreams {
 void sas_launch_sort(hipStream_t st, const SasScene &s, int tiles, const SasFrame &f, const SasSortStreams &ss);
 void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
                       bool fast_exp, bool want_max);
-// ev_start/ev_stop (optional): stamped with the kernel's own begin/end (hipExtLaunchKernelGGL)
+// ev_start/ev_stop (optional): stamped with the kernel's own begin/end (hipExtLaunchKernelGGL).
+// quad: four workgroups per tile, one per 8x8 quadrant (small frames; sas_tiles_lazy_quad_ok says whether the
+// build has that layout for the requested exponential); tile_max then holds 4 x tiles entries.
+bool sas_tiles_lazy_quad_ok(bool fast_exp);
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                           bool fast_exp, bool want_max, hipEvent_t ev_start, hipEvent_t ev_stop);
+                           bool fast_exp, bool want_max, bool quad, hipEvent_t ev_start, hipEvent_t ev_stop);
 // depth tail: fill depth where nothing was composited (fill) and/or unproject it (points)
 void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f, bool fill, bool points);

@@ -436,6 +436,40 @@ DEV void pixel_of(int wv, int lane, int &ox, int &oy)
     oy = (wv >> 1) * 8 + (g >> 1) * 4 + (q >> 2);
 }
 
+// ---- quad layout (k_tile_lazy_quad: frames of a few hundred tiles) --------------------------------
+// FOUR workgroups per tile, one per 8x8 quadrant qd = (qx, qy); wave w of a workgroup owns the quadrant's
+// 4x4 block w; a lane is (pixel q = lane >> 2 of the block, entry slot e = lane & 3): the four lanes of a
+// DPP quad work on four consecutive queue entries of the SAME pixel.
+DEV void pixel_of_quad(int qd, int wv, int lane, int &ox, int &oy)
+{
+    const int q = lane >> 2;
+    ox = ((qd & 1) * 2 + (wv & 1)) * 4 + (q & 3);
+    oy = ((qd >> 1) * 2 + (wv >> 1)) * 4 + (q >> 2);
+}
+// bit w = block w of quadrant qd can be reached (the test of block_mask16)
+DEV unsigned block_mask4(int tx, int ty, int qd, float mx, float my, float A, float B, float C, float thr)
+{
+    const float r2 = 1.125f * (A + C) + 2.25f * fabsf(B);
+    const float lim = __builtin_amdgcn_sqrtf(thr + 0.05f) + __builtin_amdgcn_sqrtf(r2);
+    const float lim2 = lim * lim;
+    float hx[2], bx[2], hy[2], dy[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float dx = mx - ((float)(tx * SAS_TILE + 4 * ((qd & 1) * 2 + k)) + 2.0f);
+        hx[k] = (0.5f * A) * dx * dx;
+        bx[k] = B * dx;
+        dy[k] = my - ((float)(ty * SAS_TILE + 4 * ((qd >> 1) * 2 + k)) + 2.0f);
+        hy[k] = (0.5f * C) * dy[k] * dy[k];
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float sc = fma_(bx[w & 1], dy[w >> 1], hx[w & 1] + hy[w >> 1]);
+        if (!(sc > lim2)) m |= 1u << w;
+    }
+    return m;
+}
+
 // Per-pixel compositing state.  x is the pixel centre relative to the tile origin.  A terminated
 // pixel (transmittance test fired, or outside the image) is parked at x = NaN: every later sigma is
 // then NaN and fails `sigma <= thr` by itself, so the inner loop carries no "done" flag.
@@ -765,6 +799,153 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     return all_done;
 }
 
+// blend_range for the quad layout (pixel_of_quad): the same batches of 256 staged records, a 4-bit block mask
+// per entry, ONE queue per wave, and trips of FOUR entries: lane (q, e) evaluates alpha of entry k + e for pixel
+// q; the transmittance chain then runs over the four entries in order, identically in the four lanes of the
+// quad, taking alpha and colour of entry j from lane j through DPP quad broadcasts.  Same arithmetic per
+// (pixel, splat), same order per pixel as blend_range: bit-identical images.  A wave alone on its SIMD issues one
+// instruction per ~7 cycles whatever it holds in flight, so the four-wide alpha evaluation halves the
+// instructions per composited entry of the latency-bound small frames; it wastes lanes where the chip is full.
+template <int J>
+DEV float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true));
+}
+template <bool FAST_EXP, typename SlotAt>
+DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, int qd, const PixConst pc, int count, SlotAt slot_at,
+                          const BlendLds &L, PixState &p, bool &wdone)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+    bool have = false;
+    const float sE5 = vgpr_const(0x3aafa464u);
+    auto fetch = [&](int at) {
+        const int idx = at + tid;
+        have = idx < count;
+        if (have) {
+            long long id = slot_at(idx);
+            if (!SAS_IN(id, n_gauss, 231) || id >= n_gauss) id = n_gauss - 1;
+            ra = f.rec[3 * id + 0];
+            rb = f.rec[3 * id + 1];
+            rc = f.rec[3 * id + 2];
+        }
+    };
+    if (count > 0) fetch(0);
+    if (tid == 0) {
+        const float z0 = vgpr_const(0u), m1 = vgpr_const(0xbf800000u);
+        L.q0[256] = make_float4(z0, z0, z0, z0);
+        L.q1[256] = make_float4(z0, z0, m1, z0);
+        L.q2[256] = make_float4(z0, z0, z0, z0);
+    }
+    const float X0 = (float)(tx * SAS_TILE), Y0 = (float)(ty * SAS_TILE);
+    const int e = lane & 3;
+    unsigned short *wq = L.queue + wv * 1024;   // this wave's queue: 256 entries (+ the look-ahead's slack inside its 1024)
+    const char *q0b = reinterpret_cast<const char *>(L.q0);
+    const char *q1b = reinterpret_cast<const char *>(L.q1);
+    const char *q2b = reinterpret_cast<const char *>(L.q2);
+    bool all_done = false;
+    for (int at = 0; at < count; at += 256) {
+        const bool every_done = __syncthreads_and(wdone);
+        if (every_done) { all_done = true; break; }
+        unsigned ment = 0u;
+        if (have) ment = block_mask4(tx, ty, qd, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+        {
+            const float u = ra.x - X0, v = ra.y - Y0;
+            const float A = ra.z, B = ra.w, C = rb.x;
+            const float hA = 0.5f * A, hC = 0.5f * C;
+            const float bu = B * u;
+            const float k1 = -fma_(A, u, B * v);
+            const float k2 = -fma_(C, v, bu);
+            const float k0 = fma_(hA * u, u, fma_(hC * v, v, bu * v));
+            L.q0[tid] = make_float4(k0, k1, k2, hA);
+            L.q1[tid] = make_float4(hC, B, rb.z, rb.y);
+            L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);
+            L.mask[tid] = ment;
+        }
+        if (!wdone) {   // the queue starts as sentinels: 264 entries (a trip reads four, the look-ahead four more)
+            const unsigned sw = __float_as_uint(vgpr_const((256u << 4) | ((256u << 4) << 16)));
+            uint2 *z = reinterpret_cast<uint2 *>(wq) + lane;
+            z[0] = make_uint2(sw, sw);
+            if (lane < 2) z[64] = make_uint2(sw, sw);
+        }
+        __syncthreads();
+        if (at + 256 < count) fetch(at + 256);
+        if (!wdone) {
+            const int cnt = (count - at) < 256 ? (count - at) : 256;
+            int qn = 0;
+            unsigned lane16 = (unsigned)lane << 4;
+            asm volatile("" : "+v"(lane16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (64 * j >= cnt) break;
+                const int ee = j * 64 + lane;
+                const unsigned me = ee < cnt ? L.mask[ee] : 0u;
+                const bool has = (me >> wv) & 1u;
+                const unsigned long long m = __ballot(has);
+                const int below = (int)mbcnt64(m);
+                if (has && SAS_IN(qn + below, 256, 232)) wq[qn + below] = (unsigned short)(lane16 + 1024u * j);
+                qn += (int)__popcll(m);
+            }
+            const int kend = __builtin_amdgcn_readfirstlane(qn);
+            if (kend > 0) {
+                int k = 0;
+                unsigned off = wq[e];
+                do {
+                    if (!SAS_IN(off >> 4, kStage, 233)) off = 256u << 4;
+                    const float4 K = *reinterpret_cast<const float4 *>(q0b + off);
+                    const float4 H = *reinterpret_cast<const float4 *>(q1b + off);
+                    const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
+                    k += 4;
+                    off = wq[k + e];   // next trip's entry, one trip ahead
+                    const float sg = fma_(H.y, pc.xy, fma_(H.x, pc.yy, fma_(K.w, pc.xx, fma_(K.z, pc.y, fma_(K.y, p.x, K.x)))));
+                    const float E = FAST_EXP ? __expf(fmaxf(-sg, -86.0f)) : c_expf_neg(fmaxf(-sg, -86.0f), sE5);
+                    const float al = fminf(kMaxAlpha, H.w * E);
+                    // alpha of entries k .. k + 3 for this lane's pixel
+                    const float a0 = quad_bcast<0>(al), a1 = quad_bcast<1>(al), a2 = quad_bcast<2>(al), a3 = quad_bcast<3>(al);
+                    // as if no pixel terminated: T only falls, one test of the last T tells
+                    const float T0 = p.T;
+                    const float w0 = (a0 < kAlphaThr) ? 0.0f : a0 * T0;
+                    const float T1 = T0 - w0;
+                    const float w1 = (a1 < kAlphaThr) ? 0.0f : a1 * T1;
+                    const float T2 = T1 - w1;
+                    const float w2 = (a2 < kAlphaThr) ? 0.0f : a2 * T2;
+                    const float T3 = T2 - w2;
+                    const float w3 = (a3 < kAlphaThr) ? 0.0f : a3 * T3;
+                    const float T4 = T3 - w3;
+                    float v0 = w0, v1 = w1, v2 = w2, v3 = w3, Tn = T4;
+                    bool all_dead = false;
+                    if (__ballot(T4 <= kTStop)) {
+                        // the splat that ends a pixel is not added and the pixel takes nothing after it
+                        const bool s0 = T1 <= kTStop, s1 = T2 <= kTStop, s2 = T3 <= kTStop, s3 = T4 <= kTStop;   // s0 => s1 => s2 => s3
+                        v0 = s0 ? 0.0f : w0;
+                        v1 = s1 ? 0.0f : w1;
+                        v2 = s2 ? 0.0f : w2;
+                        v3 = s3 ? 0.0f : w3;
+                        Tn = s0 ? T0 : (s1 ? T1 : (s2 ? T2 : (s3 ? T3 : T4)));
+                        if (s3) p.x = __builtin_nanf("");
+                        all_dead = __all(pix_dead(p));
+                    }
+                    p.T = Tn;
+                    // acc = fma(colour of entry j (lane j of the quad), weight, acc): the broadcast rides on the
+                    // multiply-add as a DPP operand (hipcc leaves a v_mov_dpp + s_nop in front of each otherwise)
+#define SAS_QFMAC(ACC_, COL_, WGT_, J) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ACC_) : "v"(COL_), "v"(WGT_))
+#define SAS_QACC(WGT_, J) SAS_QFMAC(p.r, C.x, WGT_, J); SAS_QFMAC(p.g, C.y, WGT_, J); SAS_QFMAC(p.b, C.z, WGT_, J); SAS_QFMAC(p.d, C.w, WGT_, J)
+                    SAS_QACC(v0, 0);
+                    SAS_QACC(v1, 1);
+                    SAS_QACC(v2, 2);
+                    SAS_QACC(v3, 3);
+#undef SAS_QACC
+#undef SAS_QFMAC
+                    if (all_dead) k = kend;
+                } while (k < kend);
+            }
+            wdone = __all(pix_dead(p));
+        }
+    }
+    if (!all_done) all_done = __syncthreads_and(wdone);
+    return all_done;
+}
+
 // T0 epilogue for this thread's pixel; returns its expected depth (0 outside the image).
 DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W)
 {
@@ -885,7 +1066,7 @@ __device__ __attribute__((noinline)) void partition_by_bucket(const unsigned lon
     __syncthreads();
 }
 
-template <bool FAST_EXP, bool WANT_MAX>
+template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
 DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm)
 {
     // timing experiments only (-DSAS_TUNE_ABLATE=1: no chunk sort, =2: no compositing): wrong images
@@ -912,17 +1093,26 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();
 #endif
-    const int tile = f.tile_order[blockIdx.x];
+    // QUAD: four workgroups per tile, one per 8x8 quadrant (pixel_of_quad)
+    const int tile = f.tile_order[QUAD ? (blockIdx.x >> 2) : blockIdx.x];
+    const int qd = QUAD ? (int)(blockIdx.x & 3u) : 0;
     if (!SAS_IN(tile, f.n_tiles, 213)) return;   // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
     int ox, oy;
-    pixel_of(wv, lane, ox, oy);
-    const int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
-    const PixConst pc = pix_const(ox, oy);
-    const bool inside = ix < c.W && iy < c.H;
+    if (QUAD) pixel_of_quad(qd, wv, lane, ox, oy);
+    else pixel_of(wv, lane, ox, oy);
+    int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
+    PixConst pc = pix_const(ox, oy);
+    bool inside = ix < c.W && iy < c.H;
+    bool writer = !QUAD || (lane & 3) == 0;   // QUAD: the four lanes of a pixel hold the same state, one stores it
     PixState p = pix_init(inside, ox);
     bool wdone = __all(!inside);
+    // composite `count` ordered entries in this kernel's layout
+    auto blend = [&](int count, auto slot_at) -> bool {
+        if constexpr (QUAD) return blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone);
+        else return blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone);
+    };
 
     const long long beg = f.tile_offset[tile];
     long long end = f.tile_offset[tile + 1];
@@ -997,7 +1187,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             }
         }
 #endif
-        if (!(ablate & 2)) blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+        if (!(ablate & 2)) blend(n, [&](int i) { return (long long)lo32(ck[i]); });
     } else if (n > kChunk) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
         constexpr int U = SAS_TUNE_U;
@@ -1036,11 +1226,14 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         }
         __syncthreads();
         int b_next = 0;
-        bool bail = false;
+        // QUAD: the complete ordering below works in place on the tile's segments, which the four workgroups of
+        // a tile share; so the decision is taken here, from the histogram all four see alike, and quadrant 0
+        // alone renders such a tile (in the ordinary layout) while the others leave
+        bool bail = QUAD ? (bool)__syncthreads_or(s_hist[tid] > (unsigned)kChunk) : false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
         int p_consumed = 0;                       // ... and this many of them have been composited since
         int *const ids = f.sorted_ids + beg;      // ... as storage slots in the tile's (otherwise unused) id segment
-        for (;;) {
+        while (!bail) {
             // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
             //      whose running count from b0 stays <= kChunk.  Thread t owns bucket t.
             unsigned my_hv, my_incl;
@@ -1087,7 +1280,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             //      chunk instead of scanning the whole list again (n^2 / 512 key reads on a long translucent list;
             //      only worth it when many rounds are still to come: kPartitionMin).
             //      Bucket t of the remainder starts at the exclusive count of buckets b_next .. t - 1: the scan above.
-            if (!partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
+            if (!QUAD && !partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {   // (the id segment is shared by a tile's four QUAD workgroups)
                 s_cur[tid] = my_incl - my_hv;
                 __syncthreads();
                 partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
@@ -1148,8 +1341,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             }
             bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
-                all_done = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, m,
-                                                 [&](int i) { return (long long)lo32(ck[i]); }, L, p, wdone);
+                all_done = blend(m, [&](int i) { return (long long)lo32(ck[i]); });
             if (all_done) break;
             if (partitioned) p_consumed += m;
             b_next = b1 + 1;
@@ -1158,17 +1350,29 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         if (bail) {
             // More than kChunk entries in one depth bucket (e.g. thousands of coplanar splats): order
             // the whole segment in place (slow, rare) and composite it from scratch.
-            if (tid == 0) atomicAdd(&f.stats[6], 1u);
-            int *out = f.sorted_ids + beg;
-            sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
-            __syncthreads();
-            p = pix_init(inside, ox);
-            wdone = __all(!inside);
-            blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
+            if (QUAD && qd != 0) {
+                writer = false;
+            } else {
+                if (tid == 0) atomicAdd(&f.stats[6], 1u);
+                int *out = f.sorted_ids + beg;
+                sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
+                __syncthreads();
+                if (QUAD) {   // the whole tile, ordinary layout
+                    pixel_of(wv, lane, ox, oy);
+                    ix = tx * SAS_TILE + ox;
+                    iy = ty * SAS_TILE + oy;
+                    pc = pix_const(ox, oy);
+                    inside = ix < c.W && iy < c.H;
+                    writer = true;
+                }
+                p = pix_init(inside, ox);
+                wdone = __all(!inside);
+                blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
+            }
         }
     }
-    const float ED = write_pixel(o, p, inside, ix, iy, c.W);
-    if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+    const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W);
+    if (WANT_MAX) store_tile_max(f, QUAD ? 4 * tile + qd : tile, ED, s_wmax);   // QUAD: one slot per quadrant (k_depth_tail reduces 4 x tiles)
 #ifdef SAS_TUNE_WGTIME
     if (tid == 0 && blockIdx.x < kDbgWgMax) {
         g_dbg_wg[3 * blockIdx.x] = t_wg0;
@@ -1179,16 +1383,16 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
 }
 
 #define SAS_LAZY_ATTRS __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC)))
-template <bool FAST_EXP, bool WANT_MAX>
+template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
 __global__ SAS_LAZY_ATTRS void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss, const int *perm)
 {
-    tile_lazy_body<FAST_EXP, WANT_MAX>(P, f, n_gauss, perm);
+    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(P, f, n_gauss, perm);
 }
 // all views of a group in one launch: blockIdx.y = view
-template <bool FAST_EXP, bool WANT_MAX>
+template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
 __global__ SAS_LAZY_ATTRS void k_tile_lazy_multi(SasMulti mf, long long n_gauss, const int *perm)
 {
-    tile_lazy_body<FAST_EXP, WANT_MAX>(mf.P[blockIdx.y], mf.f[blockIdx.y], n_gauss, perm);
+    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(mf.P[blockIdx.y], mf.f[blockIdx.y], n_gauss, perm);
 }
 
 // Depth tail, one pass over the depth image after the tile kernel.
@@ -1317,50 +1521,61 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 }
 
 // Production path: lazy ordering + compositing of every tile in one launch.
-template <bool FAST, bool WMAX>
+// quad: four workgroups per tile (pixel_of_quad), for frames of a few hundred tiles; exact exponential only
+// (SAS_FAST_EXP frames take the ordinary layout).  The caller sizes tile_max for 4 x tiles and passes 4 x tiles
+// to sas_launch_depth_tail when it chose quad.
+template <bool FAST, bool WMAX, bool QUAD>
 static void launch_lazy(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *perm,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
-        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm);
+        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm);
     else
-        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm);
+        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm);
 }
 
+bool sas_tiles_lazy_quad_ok(bool fast_exp) { return !fast_exp; }
+
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
-                           bool fast_exp, bool want_max, hipEvent_t ev_start, hipEvent_t ev_stop)
+                           bool fast_exp, bool want_max, bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const unsigned grid = (unsigned)tiles;
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
-        if (want_max) launch_lazy<true, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
-        else launch_lazy<true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy<true, true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<true, false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+    } else if (quad) {
+        if (want_max) launch_lazy<false, true, true>(st, 4 * grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<false, false, true>(st, 4 * grid, P, f, n, s.perm, ev_start, ev_stop);
     } else {
-        if (want_max) launch_lazy<false, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
-        else launch_lazy<false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy<false, true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<false, false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
     }
 }
 
-template <bool FAST, bool WMAX>
+template <bool FAST, bool WMAX, bool QUAD>
 static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, long long n, const int *perm, hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
-        hipExtLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX>), grid, dim3(kLazyThreads), 0, st, e0, e1, 0, mf, n, perm);
+        hipExtLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), 0, st, e0, e1, 0, mf, n, perm);
     else
-        hipLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX>), grid, dim3(kLazyThreads), 0, st, mf, n, perm);
+        hipLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), 0, st, mf, n, perm);
 }
 
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
-                                 hipEvent_t ev_start, hipEvent_t ev_stop)
+                                 bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid((unsigned)tiles, (unsigned)mf.nv);
+    const dim3 grid((unsigned)tiles, (unsigned)mf.nv), grid4(4u * (unsigned)tiles, (unsigned)mf.nv);
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
-        if (want_max) launch_lazy_multi<true, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
-        else launch_lazy_multi<true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy_multi<true, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<true, false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+    } else if (quad) {
+        if (want_max) launch_lazy_multi<false, true, true>(st, grid4, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<false, false, true>(st, grid4, mf, n, s.perm, ev_start, ev_stop);
     } else {
-        if (want_max) launch_lazy_multi<false, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
-        else launch_lazy_multi<false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy_multi<false, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<false, false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
     }
 }
 

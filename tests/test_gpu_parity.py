@@ -602,6 +602,66 @@ def _rand_rot(rng):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
+@pytest.mark.parametrize("quad", ["0", "1"])
+def test_both_tile_kernel_layouts(monkeypatch, quad):
+    """The tile kernel has two layouts: one workgroup per tile (16-lane groups walk their 4x4 block's queue, two
+    entries per trip) and, for frames of a few hundred tiles, four workgroups per tile (SAS_QUAD: one wave per 4x4
+    block, the four lanes of a DPP quad evaluate four consecutive entries of one pixel).  Left to itself the library
+    picks by tile count, so here each layout is forced onto every kind of frame: a twin fixture with thousands of
+    entries per tile, an image whose size is not a multiple of 16, coplanar splats (a crowded depth bucket: the
+    complete ordering, which under SAS_QUAD quadrant 0 performs alone for the whole tile), long translucent lists
+    (many rounds), the per-quadrant depth maxima behind SAS_DEPTH_FILL_MAX, a launch group, and a frame far past
+    the automatic threshold.  All bit-identical to the oracle."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_QUAD", quad)
+    r = Rasterizer("cuda:0")
+    try:
+        g = load_twin_fixture("dense")
+        means, op, colors, kw = twin_scene_kwargs(g)
+        W, H = [int(v) for v in g["wh"]]
+        r.upload(means, op, colors, quats=kw.get("quats"), scales=kw.get("scales"), sh_degree=kw["sh_degree"])
+        bg = tuple(float(v) for v in g["background"])
+        out = r.render(g["viewmat"], g["K"], W, H, bg, want=("rgb", "alpha", "depth"))
+        ref = oracle.render(means, op, colors, g["viewmat"], g["K"], W, H, background=bg, **kw)
+        for k in ("rgb", "alpha", "depth"):
+            assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+        # ragged image, depth fill (per-tile / per-quadrant maxima)
+        sc = make_scene(3000, seed=31, log_scale_mean=float(np.log(0.05)))
+        _upload(r, sc)
+        _compare(r, sc, ring_camera(75, 53, 70.0), depth_fill=True)
+        # crowded depth bucket -> complete ordering
+        rng = np.random.default_rng(21)
+        sc = make_scene(20000, seed=97, log_scale_mean=float(np.log(0.02)))
+        sc.means[:, 2] = 0.0
+        sc.means[:, :2] = rng.uniform(-0.5, 0.5, size=(sc.n, 2)).astype(np.float32)
+        sc.opacities[:] = np.clip(sc.opacities, 0.01, 0.05)
+        _upload(r, sc)
+        _compare(r, sc, ring_camera(96, 64, 90.0), depth_fill=True)
+        assert r.stats()["fallback_tiles"] > 0
+        # many rounds
+        rng = np.random.default_rng(22)
+        sc = make_scene(40000, seed=98, log_scale_mean=float(np.log(0.01)))
+        sc.means[:] = rng.uniform(-0.4, 0.4, size=sc.means.shape).astype(np.float32)
+        sc.opacities[:] = np.clip(sc.opacities, 0.004, 0.01)
+        _upload(r, sc)
+        _compare(r, sc, ring_camera(80, 64, 110.0))
+        assert r.stats()["max_tile_len"] > 4096
+        # a launch group of three views and a 1200-tile frame
+        sc = make_scene(20000, seed=555, log_scale_mean=float(np.log(0.025)))
+        _upload(r, sc)
+        cams = [ring_camera(200, 136, 170.0, yaw_deg=y) for y in (0.0, 100.0, 220.0)]
+        batch = r.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 200, 136, BG,
+                               want=("rgb", "depth"), depth_fill_max=True)
+        for i, cam in enumerate(cams):
+            ref = oracle.render_scene(sc, cam, background=BG, depth_mode=1)
+            assert np.array_equal(batch["rgb"][i].cpu().numpy(), ref["rgb"]), i
+            assert np.array_equal(batch["depth"][i].cpu().numpy(), ref["depth"]), i
+        _compare(r, sc, ring_camera(640, 480, 500.0))
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_randomised_edge_cases(rasterizer, seed):
     """Random cameras (also INSIDE the scene: near-plane culls, clamped Jacobian limits), odd image
