@@ -273,25 +273,46 @@ size_t counter_bytes(int tiles)
     return (cbytes + 15) & ~(size_t)15;
 }
 
+// what the prologue / epilogue kernels of a frame (or of the n frames of a pair / launch group) touch
+SasFrameIo frame_io(sas_ctx *c, Slot *const *sl, int n)
+{
+    SasFrameIo io{};
+    io.nv = n;
+    for (int k = 0; k < n; ++k) {
+        const int tiles = sl[k]->cam.tw * sl[k]->cam.th;
+        io.params_dev[k] = (SasParams *)sl[k]->params_dev.p;
+        io.params_host[k] = sl[k]->params_host;
+        io.counters[k] = (unsigned *)sl[k]->scr.counters.p;
+        io.counter_words[k] = (int)(counter_bytes(tiles) / sizeof(unsigned));
+        io.stats_host[k] = sl[k]->stats_host;
+    }
+    if (c->scene.group_Rt) {   // frames in flight at the same time carry the same poses: set_group_poses drains first
+        io.groups_dev = (float *)c->groups.p;
+        io.groups_host = c->groups_pinned;
+        io.group_floats = 12 * c->scene.n_groups;
+    }
+    return io;
+}
+
 // Uploads and clears that depend on nothing on the GPU: the slot's parameter block and counters (for
 // a pair leader also the follower's) and the group poses.  Issued BEFORE the stream waits for the
-// caller's stream and for the frame two back, so that these five small blit kernels (~6 us each, one
-// after the other) run while the previous frames are still compositing instead of in front of the
-// projection.
+// caller's stream and for the frame two back, so that it runs while the previous frames are still compositing
+// instead of in front of the projection.  For a view pair, a launch group or a scene with group poses ONE kernel
+// (k_frame_prologue) reads the pinned host blocks itself: as runtime blits these were three to five ~6 us
+// commands one after the other (Gym-camera step 208 -> 193 us, view pairs +1.3 %).
 int enqueue_prologue(sas_ctx *c, Slot &sl, hipStream_t st, int role, Slot *partner)
 {
     if (role == ROLE_FOLLOWER) return SAS_OK;
-    const int tiles = sl.cam.tw * sl.cam.th;
-    HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(sl.scr.counters.p, 0, counter_bytes(tiles), st));
-    if (role == ROLE_LEADER) {
-        const int ptiles = partner->cam.tw * partner->cam.th;
-        HIP_TRY(c, hipMemcpyAsync(partner->params_dev.p, partner->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(partner->scr.counters.p, 0, counter_bytes(ptiles), st));
+    if (role == ROLE_SINGLE && !c->scene.group_Rt) {
+        // two blits: the copy engines take them beside the compute queues, which measured 2-3 % better for single
+        // views in flight than a kernel (and the same for a blocking frame)
+        const int tiles = sl.cam.tw * sl.cam.th;
+        HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(sl.scr.counters.p, 0, counter_bytes(tiles), st));
+        return SAS_OK;
     }
-    if (c->scene.group_Rt)   // frames in flight at the same time carry the same poses: set_group_poses drains first
-        HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups,
-                                  hipMemcpyHostToDevice, st));
+    Slot *mem[2] = {&sl, partner};
+    sas_launch_frame_prologue(st, frame_io(c, mem, role == ROLE_LEADER ? 2 : 1));
     return SAS_OK;
 }
 
@@ -438,11 +459,9 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     for (int k = 0; k < n; ++k) {
         mf.f[k] = frame_of(c, sl[k]->scr, tiles);
         mf.P[k] = (const SasParams *)sl[k]->params_dev.p;
-        HIP_TRY(c, hipMemcpyAsync(sl[k]->params_dev.p, sl[k]->params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(sl[k]->scr.counters.p, 0, counter_bytes(tiles), st));
     }
-    if (c->scene.group_Rt)
-        HIP_TRY(c, hipMemcpyAsync(c->groups.p, c->groups_pinned, sizeof(float) * 12 * c->scene.n_groups, hipMemcpyHostToDevice, st));
+    const SasFrameIo io = frame_io(c, sl, n);
+    sas_launch_frame_prologue(st, io);
     HIP_TRY(c, hipEventRecord(ld.start, a.stream));
     sas_launch_project_multi(st, c->scene, mf);
     sas_launch_scan_multi(st, tiles, mf);
@@ -461,8 +480,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, mf.P[k], mf.f[k], fill, pts);
     }
     HIP_TRY(c, hipEventRecord(ld.gpu_done, st));
-    for (int k = 0; k < n; ++k)
-        HIP_TRY(c, hipMemcpyAsync(sl[k]->stats_host, sl[k]->scr.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    sas_launch_frame_epilogue(st, io);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ld.done, st));
     for (int k = 0; k < n; ++k) {

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define SAS_TILE 16
+#define SAS_MAX_GROUP 4   // views per launch group (SasMulti)
 
 // Per-frame camera constants, computed on the host with the same f32 operations the oracle uses.
 struct SasCam {
@@ -80,12 +81,29 @@ struct SasParams {
 
 // Up to SAS_MAX_GROUP same-sized views rendered by ONE set of launches (grid.y = view): the cameras of a Gym
 // step.  Passed to the *_multi kernels by value.
-#define SAS_MAX_GROUP 4
 struct SasMulti {
     SasFrame f[SAS_MAX_GROUP];
     const SasParams *P[SAS_MAX_GROUP];
     int nv;
 };
+
+// Frame prologue / epilogue as ONE small kernel each instead of a chain of runtime blits (each hipMemcpyAsync /
+// hipMemsetAsync of a few hundred bytes is its own ~6 us command on the stream): the prologue kernel copies the
+// views' parameter blocks and the group poses from PINNED HOST memory (read over PCIe by the kernel itself) and
+// zeroes the counter blocks; the epilogue kernel writes the views' 8 statistics words to pinned host memory.
+struct SasFrameIo {
+    int nv;
+    SasParams *params_dev[SAS_MAX_GROUP];
+    const SasParams *params_host[SAS_MAX_GROUP];   // pinned
+    unsigned *counters[SAS_MAX_GROUP];              // zeroed: counter_words[k] words (stats + tile counts)
+    int counter_words[SAS_MAX_GROUP];
+    unsigned *stats_host[SAS_MAX_GROUP];            // pinned, 8 words each (epilogue)
+    float *groups_dev;                              // or nullptr
+    const float *groups_host;                       // pinned
+    int group_floats;
+};
+void sas_launch_frame_prologue(hipStream_t st, const SasFrameIo &io);
+void sas_launch_frame_epilogue(hipStream_t st, const SasFrameIo &io);
 
 // launchers (sas_kernels.hip)
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,

@@ -570,6 +570,28 @@ DEV void scan_body(const SasFrame &f, int tiles)
 __global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles) { scan_body(f, tiles); }
 __global__ __launch_bounds__(1024) void k_scan_multi(SasMulti mf, int tiles) { scan_body(mf.f[blockIdx.y], tiles); }
 
+// ---- frame prologue / epilogue (SasFrameIo) ----------------------------------------------------------
+// grid = (blocks covering the largest counter block, views).  The parameter block and the group poses come
+// straight from pinned host memory: a few hundred bytes, read once, by the first block of each view.
+__global__ __launch_bounds__(256) void k_frame_prologue(SasFrameIo io)
+{
+    const int v = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < io.counter_words[v]) io.counters[v][i] = 0u;
+    if (blockIdx.x == 0) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(io.params_host[v]);
+        unsigned *dst = reinterpret_cast<unsigned *>(io.params_dev[v]);
+        for (int k = threadIdx.x; k < (int)(sizeof(SasParams) / sizeof(unsigned)); k += 256) dst[k] = src[k];
+        if (v == 0 && io.groups_dev)
+            for (int k = threadIdx.x; k < io.group_floats; k += 256) io.groups_dev[k] = io.groups_host[k];
+    }
+}
+__global__ __launch_bounds__(64) void k_frame_epilogue(SasFrameIo io)
+{
+    const int v = threadIdx.x >> 3, w = threadIdx.x & 7;
+    if (v < io.nv) io.stats_host[v][w] = io.counters[v][w];
+}
+
 // ---- k_scatter: T3 emit ---------------------------------------------------------------------------
 // Same window as k_project: count in LDS, reserve one contiguous run per touched tile with a
 // single returning global atomic, then rank inside the run with LDS atomics.  Key = depth bits << 32
@@ -698,6 +720,18 @@ void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const S
 {
     if (s.n <= 0) return;
     hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 255) / 256), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
+}
+
+void sas_launch_frame_prologue(hipStream_t st, const SasFrameIo &io)
+{
+    static_assert(sizeof(SasParams) % sizeof(unsigned) == 0, "parameter block is copied word by word");
+    int words = 1;
+    for (int v = 0; v < io.nv; ++v) words = io.counter_words[v] > words ? io.counter_words[v] : words;
+    hipLaunchKernelGGL(k_frame_prologue, dim3((unsigned)((words + 255) / 256), (unsigned)io.nv), dim3(256), 0, st, io);
+}
+void sas_launch_frame_epilogue(hipStream_t st, const SasFrameIo &io)
+{
+    hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(64), 0, st, io);
 }
 
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)
