@@ -1034,6 +1034,10 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
 #define SAS_TUNE_U 8
 #endif
 constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per round
+#ifndef SAS_TUNE_QCHUNK
+#define SAS_TUNE_QCHUNK 1024
+#endif
+constexpr int kChunkQuad = SAS_TUNE_QCHUNK;   // ... in the quad layout
 #ifndef SAS_TUNE_RANKMAX
 #define SAS_TUNE_RANKMAX 32
 #endif
@@ -1076,7 +1080,10 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     constexpr int ablate = 0;
 #endif
     // LDS: the chunk of keys, then a region shared in time by the sort scratch and the blend staging
-    __shared__ unsigned long long ck[kChunk];                                       // 8 KiB
+    // entries ordered and composited per round: in the quad layout (frames of a few hundred tiles: the chip is not
+    // full, every round's passes and barriers sit on the chain of a wave that is alone on its SIMD) twice as many
+    constexpr int CH = QUAD ? kChunkQuad : kChunk;
+    __shared__ unsigned long long ck[CH];                                           // 4 KiB (quad layout: 8 KiB)
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];    // 21 KiB
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_wsum[4], s_wmax[4];
@@ -1120,9 +1127,9 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     const int n = (int)(end - beg);
     const unsigned long long *g = f.keys + beg;
 
-    if (n > 0 && n <= kChunk) {
+    if (n > 0 && n <= CH) {
         // ---- short list: one pass, keys loaded once into registers, whole list is the chunk
-        constexpr int NK = kChunk / kLazyThreads;
+        constexpr int NK = CH / kLazyThreads;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         s_hist[tid] = 0u;
         __syncthreads();
@@ -1176,7 +1183,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                     const unsigned rel = hi32(kk[u]) - dmin;
                     if (SAS_IN(rel >> shift, 256, 220)) {
                         const unsigned pos = atomicAdd(&s_cur[rel >> shift], 1u);   // leaves the END of every bucket
-                        if (SAS_IN(pos, kChunk, 221)) ck[pos] = ((unsigned long long)rel << 32) | lo32(kk[u]);
+                        if (SAS_IN(pos, CH, 221)) ck[pos] = ((unsigned long long)rel << 32) | lo32(kk[u]);
                     }
                 }
             }
@@ -1188,7 +1195,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         }
 #endif
         if (!(ablate & 2)) blend(n, [&](int i) { return (long long)lo32(ck[i]); });
-    } else if (n > kChunk) {
+    } else if (n > CH) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
         constexpr int U = SAS_TUNE_U;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
@@ -1229,13 +1236,13 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         // QUAD: the complete ordering below works in place on the tile's segments, which the four workgroups of
         // a tile share; so the decision is taken here, from the histogram all four see alike, and quadrant 0
         // alone renders such a tile (in the ordinary layout) while the others leave
-        bool bail = QUAD ? (bool)__syncthreads_or(s_hist[tid] > (unsigned)kChunk) : false;
+        bool bail = QUAD ? (bool)__syncthreads_or(s_hist[tid] > (unsigned)CH) : false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
         int p_consumed = 0;                       // ... and this many of them have been composited since
         int *const ids = f.sorted_ids + beg;      // ... as storage slots in the tile's (otherwise unused) id segment
         while (!bail) {
             // ---- next bucket range [b0, b1]: b0 = first non-empty bucket >= b_next, b1 = last bucket
-            //      whose running count from b0 stays <= kChunk.  Thread t owns bucket t.
+            //      whose running count from b0 stays <= CH.  Thread t owns bucket t.
             unsigned my_hv, my_incl;
             {
                 const unsigned hv = (tid >= b_next) ? s_hist[tid] : 0u;
@@ -1252,7 +1259,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 my_incl = incl;
                 if (tid == kLazyThreads - 1) s_rem = incl;             // keys not yet consumed (buckets >= b_next)
                 const unsigned long long nz = __ballot(hv != 0u);
-                const unsigned long long fit = __ballot(hv != 0u && incl <= (unsigned)kChunk);
+                const unsigned long long fit = __ballot(hv != 0u && incl <= (unsigned)CH);
                 if (lane == 0) {
                     s_queue_u32(s_raw)[wv] = nz ? (unsigned)(wv * 64 + __ffsll((long long)nz) - 1) : 256u;          // first non-empty
                     s_queue_u32(s_raw)[4 + wv] = fit ? (unsigned)(wv * 64 + 63 - __clzll((long long)fit)) : 0xffffffffu;   // last fitting
@@ -1311,7 +1318,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                             const int b = (int)((hi32(kk[u]) - dmin) >> shift);
                             if (b >= b0 && b <= b1 && SAS_IN(b, 256, 206)) {
                                 const unsigned pos = atomicAdd(&s_cur[b], 1u);
-                                if (SAS_IN(pos, kChunk, 207)) ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
+                                if (SAS_IN(pos, CH, 207)) ck[pos] = ((unsigned long long)(hi32(kk[u]) - base) << 32) | lo32(kk[u]);
                             }
                         }
                     }
@@ -1321,7 +1328,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
                 // buckets are consumed whole and in order, so the chunk starts where the previous ones ended
                 const int st = p_consumed, cnt_chunk = (int)s_m;
                 for (int i = tid; i < cnt_chunk; i += kLazyThreads) {
-                    if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, kChunk, 217)) continue;
+                    if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, CH, 217)) continue;
                     const unsigned slot = (unsigned)ids[st + i];
                     const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? f.info[slot].z : dmin;
                     ck[i] = ((unsigned long long)(dbits - base) << 32) | slot;
@@ -1332,11 +1339,11 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             // ---- order the chunk, then composite it
             if (!(ablate & 1)) {
                 if (!big) {
-                    lds_bucket_rank_sort<kChunk / kLazyThreads>(ck, m, b0, shift, s_hist, s_cur, perm);
+                    lds_bucket_rank_sort<CH / kLazyThreads>(ck, m, b0, shift, s_hist, s_cur, perm);
                 } else {   // a crowded bucket (coplanar splats): radix passes cost the same whatever the distribution
                     const unsigned long long hi_excl = ((unsigned long long)(b1 - b0 + 1) << shift);
                     const unsigned rel_span = (unsigned)min((unsigned long long)(span - ((unsigned)b0 << shift)), hi_excl - 1ull);
-                    lds_radix_sort<4, kChunk / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
+                    lds_radix_sort<4, CH / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
                 }
             }
             bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
@@ -1348,7 +1355,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             if (b_next > 255) break;
         }
         if (bail) {
-            // More than kChunk entries in one depth bucket (e.g. thousands of coplanar splats): order
+            // More than CH entries in one depth bucket (e.g. thousands of coplanar splats): order
             // the whole segment in place (slow, rare) and composite it from scratch.
             if (QUAD && qd != 0) {
                 writer = false;
