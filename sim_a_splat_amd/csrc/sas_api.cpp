@@ -260,7 +260,10 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
 // for it and continues with its own binning and tiles.
 enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 
-// quad layout for a launch of `launch_tiles` tiles in all?
+// quad layout for a launch of `launch_tiles` tiles in all?  By the launch's own size: counting the frames in
+// flight as well measured worse -- 32 Gym cameras per step in launch groups of two run 30 % faster in the quad
+// layout than in the ordinary one even with four groups in flight (tools/vec_env_probe.py); what loses is a
+// launch that fills the chip by itself (1 200 tiles of 640x480: DESIGN.md 5.21).
 bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags)
 {
     if ((flags & SAS_FULL_SORT) || !sas_tiles_lazy_quad_ok((flags & SAS_FAST_EXP) != 0)) return false;
