@@ -97,8 +97,8 @@ struct sas_ctx {
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
-    // quad layout of the tile kernel (four workgroups per tile): -1 = for launches of at most quad_max_tiles
-    // tiles (all views of a launch group counted), 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
+    // quad layout of the tile kernel (four workgroups per tile): -1 = for views of at most quad_max_tiles
+    // tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
     int quad_mode = -1;
     int quad_max_tiles = 640;
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
@@ -260,7 +260,7 @@ SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
 // for it and continues with its own binning and tiles.
 enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 
-// quad layout for a launch of `launch_tiles` tiles in all?  By the launch's own size: counting the frames in
+// quad layout for views of `launch_tiles` tiles each?  By the view's own size: counting the frames in
 // flight as well measured worse -- 32 Gym cameras per step in launch groups of two run 30 % faster in the quad
 // layout than in the ordinary one even with four groups in flight (tools/vec_env_probe.py); what loses is a
 // launch that fills the chip by itself (1 200 tiles of 640x480: DESIGN.md 5.21).
@@ -473,7 +473,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
-    const bool quad = use_quad(c, tiles * n, a.flags);
+    const bool quad = use_quad(c, tiles, a.flags);   // by the size of one view: groups of four 300-tile views still gain (vec_env_probe)
     sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill, quad,
                                 ttiles ? ld.ev[4] : nullptr, ttiles ? ld.ev[5] : nullptr);
     for (int k = 0; k < n; ++k) {
