@@ -27,7 +27,7 @@ STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "wi
 
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (
-    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_wait", "sas_frames_completed",
+    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_render_batch_host", "sas_wait", "sas_frames_completed",
     "sas_last_error", "sas_stage_times", "sas_stage_time_means", "sas_frame_stats", "sas_read_projection", "sas_read_tile_lists",
     "sas_version",
 )
@@ -57,6 +57,7 @@ def lib() -> ctypes.CDLL:
     L.sas_render.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
     L.sas_render_rgbd.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp, vp, vp]
     L.sas_render_batch.argtypes = [vp, ci, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
+    L.sas_render_batch_host.argtypes = [vp, ci, vp, vp, ci, ci, vp, cu, vp, vp]
     L.sas_wait.argtypes = [vp]
     L.sas_frames_completed.argtypes = [vp, vp, vp]
     L.sas_last_error.argtypes = [vp]

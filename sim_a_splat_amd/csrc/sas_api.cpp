@@ -30,6 +30,7 @@ struct RenderArgs {
     unsigned flags = 0;
     float *rgb = nullptr, *alpha = nullptr, *depth = nullptr;
     uint8_t *rgb8 = nullptr;
+    uint8_t *rgb8_host = nullptr;   // sas_render_batch_host: host copy of rgb8, made on the frame's stream
     float *points = nullptr;   // RGB-D tail (sas_render_rgbd)
     uint8_t *mask = nullptr;
     float max_depth = 0.0f;
@@ -78,6 +79,9 @@ struct sas_ctx {
     std::string err;
     // scene
     DevBuf g0, g1, g2, col, groups, perm;
+    DevBuf host_stage;   // device staging of sas_render_batch_host's uint8 frames
+    const void *hostptr_last = nullptr;   // kernel_can_write_host cache
+    bool hostptr_ok = false;
     std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
@@ -276,6 +280,18 @@ size_t counter_bytes(int tiles)
     return (cbytes + 15) & ~(size_t)15;
 }
 
+// Can a kernel store to this host address (pinned / registered memory)?  One query per distinct base pointer.
+bool kernel_can_write_host(sas_ctx *c, const void *p)
+{
+    if (p == c->hostptr_last) return c->hostptr_ok;
+    hipPointerAttribute_t at{};
+    const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();   // a pageable pointer makes the query fail: not an error of ours
+    c->hostptr_last = p;
+    c->hostptr_ok = ok;
+    return ok;
+}
+
 // what the prologue / epilogue kernels of a frame (or of the n frames of a pair / launch group) touch
 SasFrameIo frame_io(sas_ctx *c, Slot *const *sl, int n)
 {
@@ -289,6 +305,7 @@ SasFrameIo frame_io(sas_ctx *c, Slot *const *sl, int n)
         io.counter_words[k] = (int)(counter_bytes(tiles) / sizeof(unsigned));
         io.stats_host[k] = sl[k]->stats_host;
     }
+    io.want_stats = 1;
     if (c->scene.group_Rt) {   // frames in flight at the same time carry the same poses: set_group_poses drains first
         io.groups_dev = (float *)c->groups.p;
         io.groups_host = c->groups_pinned;
@@ -365,6 +382,19 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role, Sl
     const bool pts = a.depth && (a.points || a.mask);
     if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
+    if (a.rgb8_host && a.rgb8) {   // frame wanted on the host: by a kernel when the destination is pinned (no copy-engine hop)
+        const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
+        if (kernel_can_write_host(c, a.rgb8_host)) {
+            SasFrameIo io{};
+            io.nv = 1;
+            io.host_src[0] = a.rgb8;
+            io.host_dst[0] = a.rgb8_host;
+            io.host_bytes = fb;
+            sas_launch_frame_epilogue(st, io);
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(a.rgb8_host, a.rgb8, fb, hipMemcpyDeviceToHost, st));
+        }
+    }
     HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
     HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return SAS_OK;
@@ -482,8 +512,26 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         const bool pts = ak.depth && (ak.points || ak.mask);
         if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, mf.P[k], mf.f[k], fill, pts);
     }
+    SasFrameIo ioe = io;
+    {   // frames wanted on the host (sas_render_batch_host): by the epilogue kernel when the destination is pinned
+        const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
+        bool any = false;
+        for (int k = 0; k < n; ++k) any = any || (sl[k]->args.rgb8_host && sl[k]->args.rgb8);
+        if (any && kernel_can_write_host(c, a.rgb8_host ? a.rgb8_host : sl[n - 1]->args.rgb8_host)) {
+            for (int k = 0; k < n; ++k) {
+                ioe.host_src[k] = sl[k]->args.rgb8_host ? sl[k]->args.rgb8 : nullptr;
+                ioe.host_dst[k] = sl[k]->args.rgb8_host;
+            }
+            ioe.host_bytes = fb;
+        } else if (any) {
+            for (int k = 0; k < n; ++k) {
+                const RenderArgs &ak = sl[k]->args;
+                if (ak.rgb8_host && ak.rgb8) HIP_TRY(c, hipMemcpyAsync(ak.rgb8_host, ak.rgb8, fb, hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
     HIP_TRY(c, hipEventRecord(ld.gpu_done, st));
-    sas_launch_frame_epilogue(st, io);
+    sas_launch_frame_epilogue(st, ioe);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ld.done, st));
     for (int k = 0; k < n; ++k) {
@@ -654,7 +702,7 @@ int sas_destroy(sas_ctx *c)
                           &sl.scr.wgvis, &sl.scr.tilemax})
             release(*b);
     }
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm}) release(*b);
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->host_stage}) release(*b);
     delete c;
     return SAS_OK;
 }
@@ -786,6 +834,7 @@ struct ViewCall {
     uint8_t *rgb8;
     float *points;
     uint8_t *mask;
+    uint8_t *rgb8_host = nullptr;
 };
 
 static int check_view(sas_ctx *c, const ViewCall &v, int width, int height)
@@ -808,6 +857,7 @@ static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, c
     a.W = width; a.H = height; a.flags = flags;
     a.rgb = v.rgb; a.alpha = v.alpha; a.depth = v.depth; a.rgb8 = v.rgb8;
     a.points = v.points; a.mask = v.mask;
+    a.rgb8_host = v.rgb8_host;
     a.use_max_depth = max_depth != nullptr;
     a.max_depth = max_depth ? *max_depth : 0.0f;
     a.stream = st;
@@ -890,16 +940,18 @@ int sas_render_rgbd(sas_ctx *c, const float *viewmat, const float *K, int width,
                        max_depth, stream);
 }
 
-int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
-                     const float *background, unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8,
-                     void *stream)
+static int render_batch_impl(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                             const float *background, unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8,
+                             uint8_t *rgb8_host, void *stream)
 {
     if (!c) return SAS_ERR_INVALID;
     if (n_views < 0 || (n_views > 0 && (!viewmats || !Ks))) return fail(c, SAS_ERR_INVALID, "bad view batch");
     const size_t px = (size_t)width * (size_t)height;
     auto view = [&](int v) {
-        return ViewCall{viewmats + 16 * v, Ks + 9 * v, rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
-                        depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, nullptr, nullptr};
+        ViewCall vc{viewmats + 16 * v, Ks + 9 * v, rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
+                    depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, nullptr, nullptr};
+        vc.rgb8_host = rgb8_host ? rgb8_host + 3 * px * v : nullptr;
+        return vc;
     };
     // Views go through the frame slots two at a time: one pass over the scene projects both
     // (timed and full-sort frames keep to one view per pass).
@@ -927,6 +979,31 @@ int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float
     }
     if (flags & SAS_ASYNC) return SAS_OK;
     return sas_wait(c);
+}
+
+int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                     const float *background, unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8,
+                     void *stream)
+{
+    return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb, alpha, depth, rgb8, nullptr, stream);
+}
+
+int sas_render_batch_host(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                          const float *background, unsigned flags, uint8_t *rgb8_host, void *stream)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!rgb8_host || (flags & SAS_ASYNC)) return fail(c, SAS_ERR_INVALID, "sas_render_batch_host: host buffer required, blocking only");
+    if (n_views <= 0) return n_views == 0 ? SAS_OK : fail(c, SAS_ERR_INVALID, "bad view batch");
+    if (width <= 0 || height <= 0) return fail(c, SAS_ERR_INVALID, "bad image size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->inflight > 0) {   // the staging buffer below may still be the target of frames in flight
+        const int rc = complete_all(c);
+        if (rc) return rc;
+    }
+    const int rc = ensure(c, c->host_stage, 3 * (size_t)width * (size_t)height * (size_t)n_views);
+    if (rc) return rc;
+    return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, nullptr, nullptr, nullptr,
+                             (uint8_t *)c->host_stage.p, rgb8_host, stream);
 }
 
 int sas_wait(sas_ctx *c)

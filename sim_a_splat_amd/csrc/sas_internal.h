@@ -98,6 +98,13 @@ struct SasFrameIo {
     unsigned *counters[SAS_MAX_GROUP];              // zeroed: counter_words[k] words (stats + tile counts)
     int counter_words[SAS_MAX_GROUP];
     unsigned *stats_host[SAS_MAX_GROUP];            // pinned, 8 words each (epilogue)
+    // frames wanted on the host (sas_render_batch_host, pinned destination): copied by the epilogue kernel itself,
+    // host_bytes each (0: none) -- a runtime copy between two kernels costs two switches between the compute
+    // queue and a copy engine, longer than the copy
+    const uint8_t *host_src[SAS_MAX_GROUP];
+    uint8_t *host_dst[SAS_MAX_GROUP];
+    size_t host_bytes;
+    int want_stats;                                 // epilogue: also write the statistics words
     float *groups_dev;                              // or nullptr
     const float *groups_host;                       // pinned
     int group_floats;

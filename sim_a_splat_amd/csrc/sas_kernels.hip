@@ -586,10 +586,26 @@ __global__ __launch_bounds__(256) void k_frame_prologue(SasFrameIo io)
             for (int k = threadIdx.x; k < io.group_floats; k += 256) io.groups_dev[k] = io.groups_host[k];
     }
 }
-__global__ __launch_bounds__(64) void k_frame_epilogue(SasFrameIo io)
+// grid = (blocks, views): block (0, 0) writes the statistics words of all views; every block copies its share of
+// its view's uint8 frame to pinned host memory, 16 bytes per lane where source, destination and size allow.
+__global__ __launch_bounds__(256) void k_frame_epilogue(SasFrameIo io)
 {
-    const int v = threadIdx.x >> 3, w = threadIdx.x & 7;
-    if (v < io.nv) io.stats_host[v][w] = io.counters[v][w];
+    if (io.want_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const int v = threadIdx.x >> 3, w = threadIdx.x & 7;
+        if (v < io.nv) io.stats_host[v][w] = io.counters[v][w];
+    }
+    if (io.host_bytes == 0) return;
+    const uint8_t *src = io.host_src[blockIdx.y];
+    uint8_t *dst = io.host_dst[blockIdx.y];
+    if (!src || !dst) return;
+    const size_t n = io.host_bytes, stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = i0; i < n / 16; i += stride) d4[i] = s4[i];
+    } else {
+        for (size_t i = i0; i < n; i += stride) dst[i] = src[i];
+    }
 }
 
 // ---- k_scatter: T3 emit ---------------------------------------------------------------------------
@@ -731,7 +747,12 @@ void sas_launch_frame_prologue(hipStream_t st, const SasFrameIo &io)
 }
 void sas_launch_frame_epilogue(hipStream_t st, const SasFrameIo &io)
 {
-    hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(64), 0, st, io);
+    unsigned blocks = 1;
+    if (io.host_bytes) {
+        const size_t units = (io.host_bytes + 16 * 256 - 1) / (16 * 256);
+        blocks = (unsigned)(units < 128 ? (units ? units : 1) : 128);
+    }
+    hipLaunchKernelGGL(k_frame_epilogue, dim3(blocks, io.host_bytes ? (unsigned)io.nv : 1u), dim3(256), 0, st, io);
 }
 
 void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)

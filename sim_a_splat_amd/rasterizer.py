@@ -229,6 +229,29 @@ class Rasterizer:
         self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
+    def render_batch_host(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
+                          background: Sequence[float] = (0.0, 0.0, 0.0), *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """C same-sized views as uint8 frames ON THE HOST (sas_render_batch_host): a pinned ``[C,H,W,3]`` uint8 CPU
+        tensor, filled on the frames' own streams right behind the tile kernels -- what Door B's ``get_render``
+        hands out (np.uint8 arrays), without a second round trip for the device-to-host copy.  ``out`` supplies the
+        tensor (CPU, uint8, contiguous; pinned for speed); otherwise a pinned one comes from torch's caching host
+        allocator, so a caller may keep what it gets."""
+        C = int(np.asarray(viewmats).shape[0]) if not isinstance(viewmats, torch.Tensor) else int(viewmats.shape[0])
+        V = self._host_f32(viewmats, 16 * C)
+        Kc = self._host_f32(Ks, 9 * C)
+        bg = self._host_f32(background, 3)
+        W, H = int(width), int(height)
+        if out is None:
+            out = torch.empty((C, H, W, 3), dtype=torch.uint8, pin_memory=True)
+        elif out.shape != (C, H, W, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device.type != "cpu":
+            raise ValueError(f"out must be a contiguous uint8 CPU tensor {(C, H, W, 3)}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._L.sas_render_batch_host(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, 0,
+                                           out.data_ptr(), stream)
+        if rc != 0:
+            self._check(rc, "sas_render_batch_host")
+        return out
+
     def wait(self) -> None:
         self._check(self._L.sas_wait(self._ctx), "sas_wait")
         self._keep = []

@@ -133,8 +133,7 @@ class SplatScene:
         wxyz = self.camera.wxyz if wxyz is None else wxyz
         position = self.camera.position if position is None else position
         V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))
-        out = self._raster.render(V, K, int(width), int(height), self.background, want=("rgb8",))
-        return out["rgb8"].cpu().numpy()
+        return self._raster.render_batch_host(V[None], K[None], int(width), int(height), self.background).numpy()[0]
 
     def get_renders(self, height: int, width: int, cam_poses, fov: Optional[float] = None) -> np.ndarray:
         """uint8 [C,H,W,3] for C same-sized cameras ``[(wxyz, position), ...]`` in one batched call."""
@@ -142,8 +141,8 @@ class SplatScene:
         f = self.camera.fov if fov is None else float(fov)
         Vs, Ks = self._views_and_Ks(int(height), int(width), np.stack([np.asarray(w, dtype=np.float64) for w, _ in cam_poses]),
                                     [p for _, p in cam_poses], f)
-        out = self._raster.render_batch(Vs, Ks, int(width), int(height), self.background, want=("rgb8",))
-        return out["rgb8"].cpu().numpy()
+        # frames land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
+        return self._raster.render_batch_host(Vs, Ks, int(width), int(height), self.background).numpy()
 
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
         self._sync()

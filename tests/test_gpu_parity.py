@@ -602,6 +602,51 @@ def _rand_rot(rng):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
+@pytest.mark.parametrize("group", ["1", "2"])
+def test_frames_delivered_to_host_memory(monkeypatch, group):
+    """sas_render_batch_host: uint8 frames copied to host memory on the frames' own streams (what get_render hands
+    out).  Equal, byte for byte, to the device frames of sas_render_batch: one view, a launch group plus a
+    remainder (and, with SAS_GROUP=1, views one at a time), pinned and pageable destinations, a frame that
+    overflows the intersection buffer on the way (rendered again, copied again); SAS_ASYNC is refused."""
+    import torch
+    from sim_a_splat_amd import _capi
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_GROUP", group)
+    r = Rasterizer("cuda:0")
+    try:
+        sc = make_scene(20000, seed=555, log_scale_mean=float(np.log(0.025)))
+        _upload(r, sc)
+        cams = [ring_camera(200, 136, 170.0, yaw_deg=y, elev=e) for y, e in ((0.0, 0.0), (70.0, 0.3), (140.0, -0.2))]
+        Vs, Ks = np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams])
+        dev = r.render_batch(Vs, Ks, 200, 136, BG, want=("rgb8",))["rgb8"].cpu()
+        host = r.render_batch_host(Vs, Ks, 200, 136, BG)
+        assert host.is_pinned() and host.device.type == "cpu" and torch.equal(host, dev)
+        pageable = torch.zeros((3, 136, 200, 3), dtype=torch.uint8)
+        assert r.render_batch_host(Vs, Ks, 200, 136, BG, out=pageable) is pageable and torch.equal(pageable, dev)
+        one = r.render_batch_host(Vs[1:2], Ks[1:2], 200, 136, BG)
+        assert torch.equal(one[0], dev[1])
+        L = _capi.lib()
+        bg = np.asarray(BG, dtype=np.float32)
+        rc = L.sas_render_batch_host(r._ctx, 3, np.ascontiguousarray(Vs, np.float32).ctypes.data, np.ascontiguousarray(Ks, np.float32).ctypes.data,
+                                     200, 136, bg.ctypes.data, _capi.SAS_ASYNC, host.data_ptr(), None)
+        assert rc != 0
+    finally:
+        r.close()
+    # overflow on the way: fresh buffers (2^20 keys), both views need more
+    r = Rasterizer("cuda:0")
+    try:
+        big = make_scene(30000, seed=444, log_scale_mean=float(np.log(0.12)))
+        _upload(r, big)
+        bc = [ring_camera(640, 480, 500.0, yaw_deg=90.0 * k) for k in range(2)]
+        out = r.render_batch_host(np.stack([c_.viewmat for c_ in bc]), np.stack([c_.K for c_ in bc]), 640, 480, BG)
+        assert r.stats()["regrows"] >= 1
+        for v in range(2):
+            ref = oracle.render_scene(big, bc[v], background=BG, want_rgb8=True)
+            assert np.array_equal(out[v].numpy(), ref["rgb8"]), v
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("quad", ["0", "1"])
 def test_both_tile_kernel_layouts(monkeypatch, quad):
     """The tile kernel has two layouts: one workgroup per tile (16-lane groups walk their 4x4 block's queue, two

@@ -23,6 +23,14 @@ for it in range(2):
         acc["poses"] += t1 - t0; acc["render"] += t2 - t1; acc["copy"] += t3 - t2
     total = time.perf_counter() - t_all
 print({k: round(v / 300 * 1e6, 1) for k, v in acc.items()}, "us per step; total", round(total / 300 * 1e6, 1), "us ->", round(300 / total), "env steps/s")
+# the same step with the frames delivered to pinned host memory by the library itself (sas_render_batch_host)
+for it in range(2):
+    t_all = time.perf_counter()
+    for s in range(300):
+        r.set_group_poses(poses[s])
+        r.render_batch_host(V, K, 320, 240, BG, out=host)
+    total_h = time.perf_counter() - t_all
+print("frames to the host inside the call:", round(total_h / 300 * 1e6, 1), "us per step ->", round(300 / total_h), "env steps/s")
 for k in range(3):
     out = r.render_batch(V, K, 320, 240, BG, want=("rgb8",), block=True)
     r.render(cams[0].viewmat, cams[0].K, 320, 240, BG, want=("rgb8",), timing=True)

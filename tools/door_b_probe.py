@@ -19,7 +19,7 @@ for mode in ("batch", "loop"):
         for s in range(steps):
             r.set_group_poses(random_group_poses(8, seed=s))     # per-step link poses (draw_handler)
             if mode == "batch":
-                out = r.render_batch(V, K, 320, 240, BG, want=("rgb8",))["rgb8"].cpu()
+                out = r.render_batch_host(V, K, 320, 240, BG)      # pinned host tensor, filled inside the call
             else:
                 out = [r.render(c.viewmat, c.K, 320, 240, BG, want=("rgb8",))["rgb8"].cpu() for c in cams]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

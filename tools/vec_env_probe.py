@@ -18,6 +18,6 @@ for E in [int(a) for a in sys.argv[1:]] or [1, 4, 16]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for s in range(steps):
             r.set_group_poses(random_group_poses(8, seed=s))
-            out = r.render_batch(V, K, 320, 240, BG, want=("rgb8",))["rgb8"].cpu()
+            out = r.render_batch_host(V, K, 320, 240, BG)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{E} envs: {steps/dt:.0f} steps/s = {2*E*steps/dt:.0f} frames/s ({2*E} cameras of 240x320 per step, uint8 to host)")
