@@ -80,8 +80,6 @@ struct sas_ctx {
     // scene
     DevBuf g0, g1, g2, col, groups, perm;
     DevBuf host_stage;   // device staging of sas_render_batch_host's uint8 frames
-    const void *hostptr_last = nullptr;   // kernel_can_write_host cache
-    bool hostptr_ok = false;
     std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
@@ -280,15 +278,14 @@ size_t counter_bytes(int tiles)
     return (cbytes + 15) & ~(size_t)15;
 }
 
-// Can a kernel store to this host address (pinned / registered memory)?  One query per distinct base pointer.
+// Can a kernel store to this host address (pinned / registered memory)?  Asked on every call: remembering the
+// answer per address would be wrong the day a pinned block is freed and a pageable one takes its place.
 bool kernel_can_write_host(sas_ctx *c, const void *p)
 {
-    if (p == c->hostptr_last) return c->hostptr_ok;
+    (void)c;
     hipPointerAttribute_t at{};
     const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
     (void)hipGetLastError();   // a pageable pointer makes the query fail: not an error of ours
-    c->hostptr_last = p;
-    c->hostptr_ok = ok;
     return ok;
 }
 
