@@ -61,7 +61,8 @@ enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path onl
 /* sas_frame_stats slots (int64) of the last completed frame */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
-       SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */, SAS_S_COUNT };
+       SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */,
+       SAS_S_QUAD_LAYOUT /* 1: the frame's tile kernel ran in its quad layout (four workgroups per tile) */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);

@@ -66,6 +66,7 @@ struct Slot {
     Scratch scr;
     SasCam cam{};
     bool busy = false, timed = false, timed_tiles = false;
+    bool quad = false;   // the frame's tile kernel was launched in its quad layout
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
     // per-frame parameter block (pinned host mirror + device copy)
     SasParams *params_host = nullptr;
@@ -109,7 +110,7 @@ struct sas_ctx {
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
-    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     double stage_sum[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
@@ -372,6 +373,7 @@ int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role, Sl
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
     const bool quad = !full && use_quad(c, tiles, a.flags);
+    sl.quad = quad;
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill, quad,
                                ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
@@ -501,6 +503,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
     const bool quad = use_quad(c, tiles, a.flags);   // by the size of one view: groups of four 300-tile views still gain (vec_env_probe)
+    for (int k = 0; k < n; ++k) sl[k]->quad = quad;
     sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill, quad,
                                 ttiles ? ld.ev[4] : nullptr, ttiles ? ld.ev[5] : nullptr);
     for (int k = 0; k < n; ++k) {
@@ -562,6 +565,7 @@ int complete_oldest(sas_ctx *c)
             c->stats[SAS_S_REGROWS] = c->regrows;
             c->stats[SAS_S_WINDOW_MISSES] = s[5];
             c->stats[SAS_S_FALLBACK_TILES] = s[6];
+            c->stats[SAS_S_QUAD_LAYOUT] = mem[k]->quad ? 1 : 0;
             overflow = overflow || s[2] != 0;
         }
         if (sl.timed) {

@@ -703,8 +703,20 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
             assert np.array_equal(batch["rgb"][i].cpu().numpy(), ref["rgb"]), i
             assert np.array_equal(batch["depth"][i].cpu().numpy(), ref["depth"]), i
         _compare(r, sc, ring_camera(640, 480, 500.0))
+        assert r.stats()["quad_layout"] == int(quad)
     finally:
         r.close()
+
+
+def test_tile_kernel_layout_follows_the_view_size(rasterizer):
+    """Left to itself the library renders views of at most 640 tiles (SAS_QUAD_TILES) in the quad layout and larger
+    ones in the ordinary one; sas_frame_stats reports which."""
+    sc = make_scene(3000, seed=77, log_scale_mean=float(np.log(0.04)))
+    _upload(rasterizer, sc)
+    _compare(rasterizer, sc, ring_camera(320, 240, 260.0))      # 300 tiles
+    assert rasterizer.stats()["quad_layout"] == 1
+    _compare(rasterizer, sc, ring_camera(640, 480, 520.0))      # 1200 tiles
+    assert rasterizer.stats()["quad_layout"] == 0
 
 
 @pytest.mark.parametrize("seed", range(12))
