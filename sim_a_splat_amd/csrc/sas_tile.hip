@@ -1071,7 +1071,7 @@ __device__ __attribute__((noinline)) void partition_by_bucket(const unsigned lon
 }
 
 template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
-DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm)
+DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm, unsigned wg /* workgroup index within the view */)
 {
     // timing experiments only (-DSAS_TUNE_ABLATE=1: no chunk sort, =2: no compositing): wrong images
 #ifdef SAS_TUNE_ABLATE
@@ -1101,8 +1101,8 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     const unsigned long long t_wg0 = wall_clock64();
 #endif
     // QUAD: four workgroups per tile, one per 8x8 quadrant (pixel_of_quad)
-    const int tile = f.tile_order[QUAD ? (blockIdx.x >> 2) : blockIdx.x];
-    const int qd = QUAD ? (int)(blockIdx.x & 3u) : 0;
+    const int tile = f.tile_order[QUAD ? (wg >> 2) : wg];
+    const int qd = QUAD ? (int)(wg & 3u) : 0;
     if (!SAS_IN(tile, f.n_tiles, 213)) return;   // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx = tile % c.tw, ty = tile / c.tw;
@@ -1393,13 +1393,16 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
 template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
 __global__ SAS_LAZY_ATTRS void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss, const int *perm)
 {
-    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(P, f, n_gauss, perm);
+    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(P, f, n_gauss, perm, blockIdx.x);
 }
-// all views of a group in one launch: blockIdx.y = view
+// All views of a group in one launch, INTERLEAVED in dispatch order (view = blockIdx.x mod nv): workgroups are
+// handed out in blockIdx order and every view's tile list starts with its longest tiles, so with one view per
+// blockIdx.y the later views' heavy tiles would start only once the first view had been dispatched entirely.
 template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
 __global__ SAS_LAZY_ATTRS void k_tile_lazy_multi(SasMulti mf, long long n_gauss, const int *perm)
 {
-    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(mf.P[blockIdx.y], mf.f[blockIdx.y], n_gauss, perm);
+    const unsigned nv = (unsigned)mf.nv, v = blockIdx.x % nv;
+    tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(mf.P[v], mf.f[v], n_gauss, perm, blockIdx.x / nv);
 }
 
 // Depth tail, one pass over the depth image after the tile kernel.
@@ -1572,7 +1575,7 @@ static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, lon
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
                                  bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid((unsigned)tiles, (unsigned)mf.nv), grid4(4u * (unsigned)tiles, (unsigned)mf.nv);
+    const dim3 grid((unsigned)tiles * (unsigned)mf.nv), grid4(4u * (unsigned)tiles * (unsigned)mf.nv);   // views interleaved (k_tile_lazy_multi)
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
         if (want_max) launch_lazy_multi<true, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
