@@ -24,15 +24,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from sim_a_splat_amd.covariance import GSplatLoader  # noqa: E402
 from sim_a_splat_amd.env_wrapper import SplatEnvWrapper  # noqa: E402
 from sim_a_splat_amd.handler import SplatHandler  # noqa: E402
-from sim_a_splat_amd.poses import SE3, matrix_to_quat_wxyz  # noqa: E402
+from sim_a_splat_amd.poses import SE3  # noqa: E402
 from sim_a_splat_amd.synthetic import make_scene  # noqa: E402
 
 N_LINKS = 7
-
-
-def rot_z(a):
-    c, s = np.cos(a), np.sin(a)
-    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
 
 
 class SwingingArmEnv:
@@ -41,6 +36,7 @@ class SwingingArmEnv:
 
     def __init__(self):
         self.t = 0
+        self._names = [f"plant::link{i}" for i in range(N_LINKS)]
 
     def reset(self, seed=None, reset_to_state=None):
         self.t = 0
@@ -57,12 +53,12 @@ class SwingingArmEnv:
 
     def _generate_draw_msg(self):
         """lcmt_viewer_draw-shaped message (num_links, robot_num, link_name, quaternion wxyz, position)."""
-        q, p = [], []
-        for i in range(N_LINKS):
-            q.append(matrix_to_quat_wxyz(rot_z(0.3 * np.sin(0.05 * self.t + i))).tolist())
-            p.append([0.02 * np.sin(0.03 * self.t + i), 0.0, 0.0])
-        return types.SimpleNamespace(num_links=N_LINKS, robot_num=[3] * N_LINKS, quaternion=q, position=p,
-                                     link_name=[f"plant::link{i}" for i in range(N_LINKS)])
+        i = np.arange(N_LINKS)
+        half = 0.15 * np.sin(0.05 * self.t + i)                      # rotation by 2 * half about z: (cos, 0, 0, sin)
+        q = np.stack([np.cos(half), np.zeros(N_LINKS), np.zeros(N_LINKS), np.sin(half)], axis=1)
+        p = np.stack([0.02 * np.sin(0.03 * self.t + i), np.zeros(N_LINKS), np.zeros(N_LINKS)], axis=1)
+        return types.SimpleNamespace(num_links=N_LINKS, robot_num=[3] * N_LINKS, quaternion=q.tolist(), position=p.tolist(),
+                                     link_name=self._names)
 
     def close(self):
         pass
