@@ -168,10 +168,10 @@ def test_contract_deviations_from_the_textbook_formulas_stay_far_below_the_parit
     committed twin fixture -- including the dense early-terminating one, the Door-B one and the camera
     inside the cloud -- each of them alone moves no pixel by more than 5e-5 against the all-textbook
     float32 evaluation, the sigma < 0 guard never fires, and the contract as a whole stays within 5e-5 of
-    the float64 twin (north_star tolerance: 1e-4).  tools/deviation_table.py prints the numbers."""
+    the float64 twin (north_star tolerance: 1e-4).  tests/tools/deviation_table.py prints the numbers."""
     import importlib.util
     from pathlib import Path
-    spec = importlib.util.spec_from_file_location("deviation_table", Path(__file__).resolve().parent.parent / "tools" / "deviation_table.py")
+    spec = importlib.util.spec_from_file_location("deviation_table", Path(__file__).resolve().parent / "tools" / "deviation_table.py")
     dt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(dt)
     for name in CASES:

@@ -1,7 +1,7 @@
 """Effect of each deliberate departure of the arithmetic contract from gsplat's written
 formulas, measured on the committed float64-twin fixtures (CPU only; prints the table of DESIGN.md 3).
 
-    python tools/deviation_table.py            # markdown table
+    python tests/tools/deviation_table.py            # markdown table
 Columns: max |d rgb| over all pixels of
   * the float32 oracle with all four textbook forms against the float64 twin  (float32 noise floor);
   * each contract form alone (the other three textbook) against the all-textbook float32 oracle;
@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import oracle  # noqa: E402
