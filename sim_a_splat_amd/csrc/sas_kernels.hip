@@ -573,17 +573,30 @@ __global__ __launch_bounds__(1024) void k_scan_multi(SasMulti mf, int tiles) { s
 // ---- frame prologue / epilogue (SasFrameIo) ----------------------------------------------------------
 // grid = (blocks covering the largest counter block, views).  The parameter block and the group poses come
 // straight from pinned host memory: a few hundred bytes, read once, by the first block of each view.
-__global__ __launch_bounds__(256) void k_frame_prologue(SasFrameIo io)
+// The parameter blocks (and up to kInlineGroups group poses) travel in the kernel's ARGUMENT segment, which the
+// command processor hands to the kernel without a PCIe round trip; more groups than that are read from pinned host
+// memory by the kernel itself.
+constexpr int kInlineGroups = 16;
+struct SasPrologueArgs {
+    SasFrameIo io;
+    SasParams params[SAS_MAX_GROUP];
+    float groups[12 * kInlineGroups];
+    int groups_inline;
+};
+__global__ __launch_bounds__(256) void k_frame_prologue(SasPrologueArgs a)
 {
+    const SasFrameIo &io = a.io;
     const int v = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < io.counter_words[v]) io.counters[v][i] = 0u;
     if (blockIdx.x == 0) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(io.params_host[v]);
+        const unsigned *src = reinterpret_cast<const unsigned *>(&a.params[v]);
         unsigned *dst = reinterpret_cast<unsigned *>(io.params_dev[v]);
         for (int k = threadIdx.x; k < (int)(sizeof(SasParams) / sizeof(unsigned)); k += 256) dst[k] = src[k];
-        if (v == 0 && io.groups_dev)
-            for (int k = threadIdx.x; k < io.group_floats; k += 256) io.groups_dev[k] = io.groups_host[k];
+        if (v == 0 && io.groups_dev) {
+            const float *g = a.groups_inline ? a.groups : io.groups_host;
+            for (int k = threadIdx.x; k < io.group_floats; k += 256) io.groups_dev[k] = g[k];
+        }
     }
 }
 // grid = (blocks, views): block (0, 0) writes the statistics words of all views; every block copies its share of
@@ -741,9 +754,18 @@ void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const S
 void sas_launch_frame_prologue(hipStream_t st, const SasFrameIo &io)
 {
     static_assert(sizeof(SasParams) % sizeof(unsigned) == 0, "parameter block is copied word by word");
+    static_assert(sizeof(SasPrologueArgs) <= 4096, "kernel argument segment");
+    SasPrologueArgs a{};
+    a.io = io;
     int words = 1;
-    for (int v = 0; v < io.nv; ++v) words = io.counter_words[v] > words ? io.counter_words[v] : words;
-    hipLaunchKernelGGL(k_frame_prologue, dim3((unsigned)((words + 255) / 256), (unsigned)io.nv), dim3(256), 0, st, io);
+    for (int v = 0; v < io.nv; ++v) {
+        words = io.counter_words[v] > words ? io.counter_words[v] : words;
+        a.params[v] = *io.params_host[v];
+    }
+    a.groups_inline = io.groups_dev && io.group_floats <= 12 * kInlineGroups;
+    if (a.groups_inline)
+        for (int k = 0; k < io.group_floats; ++k) a.groups[k] = io.groups_host[k];
+    hipLaunchKernelGGL(k_frame_prologue, dim3((unsigned)((words + 255) / 256), (unsigned)io.nv), dim3(256), 0, st, a);
 }
 void sas_launch_frame_epilogue(hipStream_t st, const SasFrameIo &io)
 {
