@@ -88,9 +88,9 @@ struct SasMulti {
 };
 
 // Frame prologue / epilogue as ONE small kernel each instead of a chain of runtime blits (each hipMemcpyAsync /
-// hipMemsetAsync of a few hundred bytes is its own ~6 us command on the stream): the prologue kernel copies the
-// views' parameter blocks and the group poses from PINNED HOST memory (read over PCIe by the kernel itself) and
-// zeroes the counter blocks; the epilogue kernel writes the views' 8 statistics words to pinned host memory.
+// hipMemsetAsync of a few hundred bytes is its own ~6 us command on the stream): the prologue kernel receives the
+// views' parameter blocks and the group poses in its argument segment (pose sets too large for that: read from
+// PINNED HOST memory by the kernel itself) and zeroes the counter blocks; the epilogue kernel writes the views' 8 statistics words to pinned host memory.
 struct SasFrameIo {
     int nv;
     SasParams *params_dev[SAS_MAX_GROUP];
