@@ -34,7 +34,7 @@ def main():
                        np.log(sc.opacities / (1 - sc.opacities)).reshape(-1, 1), sh_degree=3, device="cuda:0")
     cam = ring_camera(640, 480, 525.0, yaw_deg=0.0)
     K = cam.K
-    gs = GaussianSplat(model, PinholeCamera(torch.eye(4)[None, :3], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+    gs = GaussianSplat.from_model(model, PinholeCamera(torch.eye(4)[None, :3], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
                                             float(K[1, 2]), cam.width, cam.height))
     H, W, _ = gs.get_camera_intrinsics()
     poses = [torch.from_numpy(c2w_opengl_from_viewmat(ring_camera(W, H, 525.0, yaw_deg=3.6 * i).viewmat)) for i in range(a.frames)]

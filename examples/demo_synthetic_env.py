@@ -72,7 +72,7 @@ def main():
 
     sc = make_scene(113_831, seed=2, n_groups=N_LINKS + 1)            # group 0 = static scene
     # what GSplatLoader hands to the handler (splat_utils.py:24-49): activated, DC colour, covariances
-    L = GSplatLoader(sc.means, sc.quats, np.log(sc.scales), sc.sh[:, 0], np.log(sc.opacities / (1 - sc.opacities)))
+    L = GSplatLoader.from_arrays(sc.means, sc.quats, np.log(sc.scales), sc.sh[:, 0], np.log(sc.opacities / (1 - sc.opacities)))
     masks = {f"link{i}": sc.group_id == i + 1 for i in range(N_LINKS)}
     handler = SplatHandler.from_arrays(L.means.numpy(), L.covs.numpy(), np.clip(L.colors.numpy(), 0, 1), L.opacities.numpy(),
                                        masks, np.eye(4), [np.eye(4)] * N_LINKS, device=0)   # masks made in the splat frame itself

@@ -14,6 +14,13 @@
     (robots-scene-v2 / xarm6-1): ICP similarity, mask-time joint configuration, dataparser
     transform and the seven per-link masks, bit-packed.  Data only; the masks' pickled .npy is
     read with the whitelisting unpickler of sim_a_splat_amd.io, never np.load(allow_pickle=True).
+(4) scene_assets_divar113vhw.npz -- the same for the ~300k scene (divar113vhw: six link masks over
+    292,247 Gaussians, ICP similarity; that scene ships no joint_config.npy).
+(5) ns_run_<scene>.npz -- the DATA FILES of both trained runs as the reference ships them, byte for byte:
+    the nerfstudio config.yml (a YAML dump), dataparser_transforms.json and the dataset's transforms.json
+    (camera intrinsics + 293 / 307 camera poses).  Tests materialise them into the reference's directory
+    layout, add a fabricated checkpoint (both real ones are Git-LFS pointers) and construct
+    GaussianSplat(config_path, ...) on it; dataparser_transforms.json pins the dataparser restatement.
 The reference tree does not exist on the GPU box; tests read only the committed fixtures.
 """
 from __future__ import annotations
@@ -143,6 +150,35 @@ def gen_scene_assets():
     print("scene_assets_xarm6_1.npz", n, [int(masks[k].sum()) for k in names])
 
 
+def gen_scene_assets_divar():
+    from sim_a_splat_amd import io
+    base = Path("/root/reference/assets/divar113vhw")
+    d = base / "masks" / "divar113vhw"
+    masks = io.load_link_masks(d / "link_masks_global_dict.npy")
+    icp = io.load_icp_transformation(d / "icp_transformation.npy")
+    T, scale = io.load_dataparser_transforms(next((base / "splatfacto").glob("*/dataparser_transforms.json")))
+    names = sorted(masks, key=lambda k: int(k[4:]))
+    n = len(masks[names[0]])
+    np.savez_compressed(GOLD / "scene_assets_divar113vhw.npz", icp_transformation=icp,
+                        polygon_bounds=np.load(d / "polygon_bounds.npy", allow_pickle=False),
+                        trans_init=np.load(d / "trans_init.npy", allow_pickle=False),
+                        dataparser_transform=T, dataparser_scale=np.float64(scale), n=np.int64(n),
+                        link_names=np.array(names), mask_bits=np.stack([np.packbits(masks[k]) for k in names]),
+                        mask_counts=np.array([int(masks[k].sum()) for k in names], np.int64))
+    print("scene_assets_divar113vhw.npz", n, [int(masks[k].sum()) for k in names])
+
+
+def gen_run_files():
+    for scene in ("divar113vhw", "robots-scene-v2"):
+        base = Path("/root/reference/assets") / scene
+        run = next((base / "splatfacto").glob("*/config.yml")).parent
+        raw = lambda p: np.frombuffer(Path(p).read_bytes(), dtype=np.uint8)
+        np.savez_compressed(GOLD / f"ns_run_{scene}.npz", scene=np.array(scene), timestamp=np.array(run.name),
+                            config_yml=raw(run / "config.yml"), dataparser_transforms_json=raw(run / "dataparser_transforms.json"),
+                            transforms_json=raw(base / "transforms.json"))
+        print(f"ns_run_{scene}.npz", run.name)
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     if REF.exists():
@@ -151,4 +187,7 @@ if __name__ == "__main__":
         print("reference tree absent: compute_cov.npz not regenerated")
     if ASSETS.exists():
         gen_scene_assets()
-    gen_twin_renders()
+        gen_scene_assets_divar()
+        gen_run_files()
+    if "--assets-only" not in sys.argv:
+        gen_twin_renders()

@@ -34,13 +34,27 @@ def compute_cov(quat: torch.Tensor, scaling: torch.Tensor, exp: bool = False) ->
 
 
 class GSplatLoader:
-    """Activated Gaussians in the attribute layout of the reference's loader
-    (sim_a_splat/splat/splat_utils.py:24-49): ``means rots scales covs covs_inv colors opacities``."""
+    """``GSplatLoader(gsplat_location, device)`` of the reference (sim_a_splat/splat/splat_utils.py:13-89): a ``str``
+    is the reference's JSON scene file, a ``Path`` the ``config.yml`` of a nerfstudio splatfacto run (loaded through
+    ``GaussianSplat(path, test_mode="inference", dataset_mode="train", device)``, kept as ``.splat``); anything else
+    raises the reference's ValueError.  Attributes: ``means rots scales covs covs_inv colors opacities``.
 
-    def __init__(self, means, quats, log_scales, features_dc, opacity_logits, device="cpu"):
-        dev = torch.device(device)
-        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
-        self.device = dev
+    ``GSplatLoader.from_arrays`` takes the raw arrays; ``GSplatLoader.from_path`` also reads a bare checkpoint, a run
+    directory without its dataset, or an ``.npz``."""
+
+    def __init__(self, gsplat_location, device="cpu"):
+        from pathlib import Path
+        self.device = device
+        if isinstance(gsplat_location, str):
+            self.load_gsplat_from_json(gsplat_location)
+        elif isinstance(gsplat_location, Path):
+            self.load_gsplat_from_nerfstudio(gsplat_location)
+        else:
+            raise ValueError("GSplat file must be either a .json or .yml file.")
+
+    def _activate(self, means, quats, log_scales, features_dc, opacity_logits) -> None:
+        dev = torch.device(self.device)
+        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32).detach().clone().to(dev)
         self.means = f32(means)
         self.rots = f32(quats)
         self.scales = torch.exp(f32(log_scales))                     # :35-36
@@ -49,19 +63,47 @@ class GSplatLoader:
         self.colors = sh2rgb(f32(features_dc).reshape(-1, 3))        # :41
         self.opacities = torch.sigmoid(f32(opacity_logits)).reshape(-1, 1)   # :43-45
 
+    def load_gsplat_from_nerfstudio(self, gsplat_location) -> None:
+        from .gaussian_splat import GaussianSplat
+        self.splat = GaussianSplat(gsplat_location, test_mode="inference", dataset_mode="train", device=self.device)
+        m = self.splat.pipeline.model
+        self._activate(m.means, m.quats, m.scales, m.features_dc, m.opacities)
+        print(f"There are {self.means.shape[0]} Gaussians in the GSplat model")
+
+    def load_gsplat_from_json(self, gsplat_location) -> None:
+        """:51-89: keys means, rotations, colors, opacities, scalings; ``colors`` are taken as given, opacities get
+        a sigmoid, scalings an exp."""
+        from . import io
+        d = io.load_json(gsplat_location)
+        dev = torch.device(self.device)
+        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        self.means, self.rots, self.colors = f32(d["means"]), f32(d["rotations"]), f32(d["colors"])
+        self.opacities = torch.sigmoid(f32(d["opacities"]))
+        self.scales = torch.exp(f32(d["scalings"]))
+        self.covs_inv = compute_cov(self.rots, 1.0 / self.scales)
+        self.covs = compute_cov(self.rots, self.scales)
+
+    @classmethod
+    def from_arrays(cls, means, quats, log_scales, features_dc, opacity_logits, device="cpu") -> "GSplatLoader":
+        """Raw (pre-activation) splatfacto parameters already in memory."""
+        self = cls.__new__(cls)
+        self.device = device
+        self._activate(means, quats, log_scales, features_dc, opacity_logits)
+        return self
+
     @classmethod
     def from_path(cls, path, device="cpu") -> "GSplatLoader":
-        """What ``GSplatLoader(path_to_gsplat, device)`` does in the reference (splat_utils.py:16-49), without
-        nerfstudio's ``eval_setup``: ``path`` is the splatfacto ``config.yml`` (its run directory holds
-        ``nerfstudio_models/step-*.ckpt``; the latest is read), a checkpoint, or a scene ``.json`` / ``.npz``."""
+        """Gaussians from whatever ``path`` names, without needing the run's dataset: the splatfacto ``config.yml``
+        or its run directory (``nerfstudio_models/step-*.ckpt``, the latest is read), a checkpoint, or a scene
+        ``.json`` / ``.npz``."""
         from pathlib import Path
         from . import io
         p = Path(path)
         if p.suffix == ".json":
-            return cls.from_json(p, device)
+            return cls(str(p), device)
         if p.suffix == ".npz":
             d = io.load_npz(p)
-            return cls(d["means"], d["quats"], d["scales"], d["features_dc"], d["opacities"], device)
+            return cls.from_arrays(d["means"], d["quats"], d["scales"], d["features_dc"], d["opacities"], device)
         if p.suffix != ".ckpt":
             run = p.parent if p.is_file() or p.suffix in (".yml", ".yaml") else p
             ckpts = sorted((run / "nerfstudio_models").glob("step-*.ckpt"))
@@ -69,21 +111,8 @@ class GSplatLoader:
                 raise FileNotFoundError(f"no nerfstudio_models/step-*.ckpt next to {path}")
             p = ckpts[-1]
         g = io.load_splatfacto_ckpt(p)
-        return cls(g["means"], g["quats"], g["scales"], g["features_dc"], g["opacities"], device)
+        return cls.from_arrays(g["means"], g["quats"], g["scales"], g["features_dc"], g["opacities"], device)
 
     @classmethod
     def from_json(cls, path, device="cpu") -> "GSplatLoader":
-        """``load_gsplat_from_json`` (splat_utils.py:51-89): keys means, rotations, colors, opacities,
-        scalings; ``colors`` are taken as given, opacities get a sigmoid, scalings an exp."""
-        from . import io
-        d = io.load_json(path)
-        self = cls.__new__(cls)
-        dev = torch.device(device)
-        f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
-        self.device = dev
-        self.means, self.rots, self.colors = f32(d["means"]), f32(d["rotations"]), f32(d["colors"])
-        self.opacities = torch.sigmoid(f32(d["opacities"]))
-        self.scales = torch.exp(f32(d["scalings"]))
-        self.covs_inv = compute_cov(self.rots, 1.0 / self.scales)
-        self.covs = compute_cov(self.rots, self.scales)
-        return self
+        return cls(str(path), device)

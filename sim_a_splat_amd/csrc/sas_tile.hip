@@ -532,13 +532,14 @@ extern "C" int sas_debug_wg(unsigned long long *out, int n)
 // [6] / [7] wave cycles waiting at the batch barrier / inside the compositing loop,
 // [8] (entry, 16-lane group) slots in which at least one lane composited, [9] slots that held the sentinel,
 // [10] slots of a group whose 16 pixels had all terminated (after the trip), [11] slots of a live group in which no lane passed the alpha test (includes sentinels)
-__device__ unsigned long long g_dbg[12];
+// [12] staged entries whose 16-bit block mask is empty (the splat reaches no 4x4 block of the tile), [13] staged entries in all waves' eyes (256 per batch)
+__device__ unsigned long long g_dbg[16];
 extern "C" int sas_debug_counters(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
 
     if (reset) {
-        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -625,6 +626,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         if (every_done) { all_done = true; break; }
         unsigned ment = 0u;
         if (have) ment = block_mask16(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+#ifdef SAS_TUNE_STATS
+        DBG_ADD(12, __popcll(__ballot(have && ment == 0u)));
+        DBG_ADD(13, __popcll(__ballot(have)));
+#endif
         // Contract T6: sigma as a polynomial in the tile-local pixel centre (x, y),
         //   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
         //   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2,

@@ -1,15 +1,23 @@
-"""Door A: the ``GaussianSplat.render(pose)`` / ``model.get_outputs_for_camera`` surface of
-sim_a_splat/ns_utils/nerfstudio_utils.py:51-177, backed by the HIP rasterizer.
+"""Door A: ``GaussianSplat`` / ``load_model`` of sim_a_splat/ns_utils/nerfstudio_utils.py:51-177,500-516 on the HIP
+rasterizer, with the reference's constructor::
 
-nerfstudio and gsplat are not dependencies: ``SplatModel`` keeps the raw splatfacto parameters
-(the ``gauss_params`` names of the checkpoint) and reproduces what ``SplatfactoModel.get_outputs``
-does around the rasterizer: activations, OpenGL->OpenCV view matrix,
-``rgb = clamp(render + (1 - alpha) * background, 0, 1)``, ``depth = where(alpha > 0, ED, max ED)``.
+    gsplat = GaussianSplat(config_path, res_factor=None, test_mode="inference", dataset_mode="test", device="cuda")
+    H, W, K = gsplat.get_camera_intrinsics()
+    out = gsplat.render(pose)            # {"rgb", "depth", "accumulation", "background"} device tensors
+
+nerfstudio and gsplat are not dependencies.  ``ns_run.eval_setup`` reads the run (config.yml, the latest
+checkpoint, the dataset's transforms.json through a restatement of the Nerfstudio dataparser); ``SplatModel`` keeps
+the raw splatfacto parameters under the names the reference reads off ``pipeline.model`` (splat_utils.py:33-45)
+and reproduces what ``SplatfactoModel.get_outputs`` does around the rasterizer: activations,
+OpenGL->OpenCV view matrix, ``rgb = clamp(render + (1 - alpha) * background, 0, 1)``,
+``depth = where(alpha > 0, ED, max ED)``.  ``GaussianSplat.from_model`` is the form with the model injected.
 """
 from __future__ import annotations
 
 import time
 from dataclasses import dataclass
+from pathlib import Path
+from types import SimpleNamespace
 from typing import Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -28,6 +36,10 @@ def viewmat_from_c2w_opengl(c2w: Union[np.ndarray, torch.Tensor]) -> np.ndarray:
     V[:3, :3] = R.T
     V[:3, 3] = -(R.T @ t)
     return V
+
+
+def _scalar(v) -> float:
+    return float(v.reshape(-1)[0]) if isinstance(v, (torch.Tensor, np.ndarray)) else float(v)
 
 
 @dataclass
@@ -67,9 +79,13 @@ class SplatModel:
 
     def _rasterizer(self) -> Rasterizer:
         if self._raster is None:
-            r = Rasterizer(self.device)
+            # eval_setup puts the model on "cuda if available" whatever device the caller names
+            # (nerfstudio_utils.py:505, eval_utils.eval_setup); there is no CPU render path here
+            r = Rasterizer(self.device if self.device.type == "cuda" else 0)
             kk = (self.sh_degree + 1) ** 2
-            colors = torch.cat([self.features_dc.reshape(-1, 1, 3), self.features_rest.reshape(-1, kk - 1, 3)], dim=1)
+            # checkpoints carry all 15 higher-order coefficients; the bands in use are the first (d+1)^2 - 1
+            rest = self.features_rest.reshape(self.num_points, -1, 3)[:, :kk - 1]
+            colors = torch.cat([self.features_dc.reshape(-1, 1, 3), rest], dim=1)
             # activations of get_outputs: exp(scales), sigmoid(opacities); quats stay un-normalised
             r.upload(self.means, torch.sigmoid(self.opacities).reshape(-1), colors, quats=self.quats,
                      scales=torch.exp(self.scales), sh_degree=self.sh_degree)
@@ -77,7 +93,8 @@ class SplatModel:
         return self._raster
 
     @torch.no_grad()
-    def get_outputs_for_camera(self, camera: PinholeCamera, obb_box=None, compute_semantics: bool = False) -> Dict[str, torch.Tensor]:
+    def get_outputs_for_camera(self, camera, obb_box=None, compute_semantics: bool = False) -> Dict[str, torch.Tensor]:
+        """``camera``: a one-camera ``ns_run.Cameras`` or a ``PinholeCamera``."""
         if obb_box is not None:
             raise NotImplementedError("crop boxes are outside the render-image path (the reference passes None)")
         if compute_semantics:
@@ -85,45 +102,117 @@ class SplatModel:
         c2w = camera.camera_to_worlds
         c2w = c2w[0] if c2w.dim() == 3 else c2w
         V = viewmat_from_c2w_opengl(c2w)
-        K = camera.get_intrinsics_matrices().numpy()
-        W, H = int(camera.width), int(camera.height)
+        K = np.array([[_scalar(camera.fx), 0.0, _scalar(camera.cx)], [0.0, _scalar(camera.fy), _scalar(camera.cy)],
+                      [0.0, 0.0, 1.0]], dtype=np.float32)
+        W, H = int(_scalar(camera.width)), int(_scalar(camera.height))
         bg = self.background_color
-        out = self._rasterizer().render(V, K, W, H, bg.tolist(), want=("rgb", "alpha", "depth"), depth_fill_max=True)
+        r = self._rasterizer()
+        out = r.render(V, K, W, H, bg.tolist(), want=("rgb", "alpha", "depth"), depth_fill_max=True)
         return {"rgb": out["rgb"], "depth": out["depth"], "accumulation": out["alpha"],
-                "background": bg.to(self.device).expand(H, W, 3)}
+                "background": bg.to(r.device).expand(H, W, 3)}
+
+
+class _Dataset:
+    """``pipeline.datamanager.{train,eval}_dataset`` as far as the reference reads it: ``.cameras`` and the
+    image file names (the images themselves are not shipped with a run)."""
+
+    def __init__(self, dp_out: Dict):
+        self.cameras = dp_out["cameras"]
+        self._dataparser_outputs = SimpleNamespace(image_filenames=[Path(f) for f in dp_out["image_filenames"]],
+                                                   dataparser_scale=dp_out["scale"], dataparser_transform=dp_out["transform"])
+
+    def __len__(self) -> int:
+        return len(self.cameras)
 
 
 class GaussianSplat:
-    """``GaussianSplat`` of the reference with the model injected instead of ``eval_setup``."""
+    """``GaussianSplat(config_path, res_factor, test_mode, dataset_mode, device)`` of the reference
+    (nerfstudio_utils.py:51-121): ``config_path`` is the ``config.yml`` of a splatfacto run."""
 
-    def __init__(self, model: SplatModel, camera: PinholeCamera, res_factor: Optional[float] = None,
-                 device: Union[torch.device, str, None] = None) -> None:
-        self.device = torch.device(device) if device is not None else model.device
-        self.model = model
+    def __init__(self, config_path: Path, res_factor=None, test_mode: str = "inference", dataset_mode: str = "test",
+                 device: Union[torch.device, str] = "cpu") -> None:
+        self.config_path = config_path
         self.res_factor = res_factor
-        if res_factor is not None:   # Cameras.rescale_output_resolution
-            camera = PinholeCamera(camera.camera_to_worlds, camera.fx * res_factor, camera.fy * res_factor,
-                                   camera.cx * res_factor, camera.cy * res_factor,
-                                   int(np.floor(camera.width * res_factor + 0.5)), int(np.floor(camera.height * res_factor + 0.5)))
-        self.camera0 = camera
+        self.device = device
+        self.init_pipeline(test_mode)
+        self.load_dataset(dataset_mode)
+        self.get_cameras()
+
+    @classmethod
+    def from_model(cls, model: SplatModel, camera, res_factor: Optional[float] = None,
+                   device: Union[torch.device, str, None] = None) -> "GaussianSplat":
+        """The same object around a model already in memory: ``camera`` (a ``PinholeCamera`` or ``ns_run.Cameras``)
+        plays the dataset's cameras (its first camera gives the intrinsics ``render`` uses)."""
+        from . import ns_run
+        self = cls.__new__(cls)
+        self.config_path, self.res_factor = None, res_factor
+        self.device = torch.device(device) if device is not None else model.device
+        self.config = None
+        if isinstance(camera, PinholeCamera):
+            c2w = camera.camera_to_worlds.reshape(-1, 3, 4)
+            camera = ns_run.Cameras(c2w, camera.fx, camera.fy, camera.cx, camera.cy, camera.width, camera.height)
+        ds = _Dataset(dict(cameras=camera, image_filenames=[], scale=1.0, transform=torch.eye(4)[:3]))
+        self.pipeline = SimpleNamespace(model=model, datamanager=SimpleNamespace(train_dataset=ds, eval_dataset=ds))
+        self.dataset = ds
+        self.get_cameras()
+        return self
+
+    # -- nerfstudio_utils.py:77-100 ------------------------------------------------------------------------
+    def init_pipeline(self, test_mode: str):
+        from . import ns_run
+        run = ns_run.eval_setup(Path(self.config_path), test_mode=test_mode)
+        g = run["gauss_params"]
+        model = SplatModel(g["means"], g["scales"], g["quats"], g["features_dc"], g["features_rest"], g["opacities"],
+                           sh_degree=run["sh_degree"], background_color=run["background"],
+                           device=self.device if torch.device(self.device).type == "cuda" else "cuda:0")
+        self.config = run["config"]
+        self._run = run
+        self.pipeline = SimpleNamespace(model=model, datamanager=SimpleNamespace(train_dataset=_Dataset(run["train"]),
+                                                                                 eval_dataset=_Dataset(run["eval"])))
+
+    def load_dataset(self, dataset_mode: str):
+        if dataset_mode == "train":
+            self.dataset = self.pipeline.datamanager.train_dataset
+        elif dataset_mode in ["val", "test"]:
+            self.dataset = self.pipeline.datamanager.eval_dataset
+        else:
+            # the reference builds this ValueError without raising it (:90-93) and then fails on self.dataset
+            raise ValueError('Incorrect value for datset_mode. Accepted values include: dataset_mode: Literal["train", "val", "test"].')
+
+    def get_cameras(self):
+        self.cameras = self.dataset.cameras
+        if self.res_factor is not None:
+            self.cameras.rescale_output_resolution(self.res_factor)
+
+    def get_poses(self):
+        return self.cameras.camera_to_worlds
 
     def get_camera_intrinsics(self) -> Tuple[int, int, torch.Tensor]:
-        return int(self.camera0.height), int(self.camera0.width), self.camera0.get_intrinsics_matrices()
+        K = self.cameras[0].get_intrinsics_matrices().squeeze()
+        W = int(self.cameras[0].width.item())
+        H = int(self.cameras[0].height.item())
+        return H, W, K
 
+    # -- :123-177 ------------------------------------------------------------------------------------------
     def render(self, pose, compute_semantics: Optional[bool] = False, debug_mode: bool = False) -> Dict[str, torch.Tensor]:
-        """``pose``: [>=3,4] camera-to-world, OpenGL axes, nerfstudio scene frame (nerfstudio_utils.py:123-177)."""
-        c2w = torch.as_tensor(pose, dtype=torch.float32)[None, :3, ...]
-        cam = PinholeCamera(c2w, self.camera0.fx, self.camera0.fy, self.camera0.cx, self.camera0.cy,
-                            self.camera0.width, self.camera0.height)
+        """``pose``: [>=3,4] camera-to-world, OpenGL axes, nerfstudio scene frame."""
+        from . import ns_run
+        camera_to_world = torch.as_tensor(pose, dtype=torch.float32)[None, :3, ...]
+        c0 = self.cameras[0]
+        cameras = ns_run.Cameras(camera_to_world, c0.fx, c0.fy, c0.cx, c0.cy, c0.width, c0.height)
         tnow = time.perf_counter()
         try:
-            outputs = self.model.get_outputs_for_camera(cam, obb_box=None, compute_semantics=compute_semantics)
+            outputs = self.pipeline.model.get_outputs_for_camera(cameras, obb_box=None, compute_semantics=compute_semantics)
         except TypeError:
-            outputs = self.model.get_outputs_for_camera(cam, obb_box=None)
+            outputs = self.pipeline.model.get_outputs_for_camera(cameras, obb_box=None)
         if debug_mode:
-            torch.cuda.synchronize(self.device)
+            torch.cuda.synchronize(outputs["rgb"].device)
             print("Rendering time: ", time.perf_counter() - tnow)
         return outputs
+
+    @property
+    def model(self) -> SplatModel:
+        return self.pipeline.model
 
     def generate_RGBD_point_cloud(self, pose, max_depth: Optional[float] = 1.0):
         """RGB-D consumer of nerfstudio_utils.py:375-472 (tensor results only; the open3d cloud is
@@ -132,8 +221,16 @@ class GaussianSplat:
         c2w = torch.as_tensor(pose, dtype=torch.float32)[:3, ...]
         V = viewmat_from_c2w_opengl(c2w)
         H, W, K = self.get_camera_intrinsics()
-        bg = self.model.background_color
-        out = self.model._rasterizer().render_rgbd(V, K.numpy(), W, H, bg.tolist(), max_depth=max_depth)
+        model = self.pipeline.model
+        bg = model.background_color
+        r = model._rasterizer()
+        out = r.render_rgbd(V, K.numpy(), W, H, bg.tolist(), max_depth=max_depth)
         outputs = {"rgb": out["rgb"], "depth": out["depth"], "accumulation": out["alpha"],
-                   "background": bg.to(self.device).expand(H, W, 3)}
+                   "background": bg.to(r.device).expand(H, W, 3)}
         return out["rgb"], out["points"], None, out["mask"], outputs
+
+
+def load_model(config_path: Path) -> GaussianSplat:
+    """``load_model`` of the reference (nerfstudio_utils.py:500-516)."""
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    return GaussianSplat(config_path=config_path, res_factor=None, test_mode="test", dataset_mode="val", device=device)

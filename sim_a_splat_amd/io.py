@@ -39,23 +39,29 @@ CKPT_PREFIX = "_model.gauss_params."
 CKPT_FIELDS = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
 
 
-def load_splatfacto_ckpt(path, trust_pickle: bool = False) -> Dict[str, np.ndarray]:
-    """``gauss_params`` of a nerfstudio 1.1.x splatfacto checkpoint (``pipeline`` state dict).
+def load_splatfacto_ckpt(path, trust_pickle: bool = False, with_step: bool = False):
+    """``gauss_params`` of a nerfstudio 1.1.x splatfacto checkpoint (``pipeline`` state dict; a ``module.`` prefix
+    left by DistributedDataParallel is dropped, as ``Pipeline.load_pipeline`` does).
 
     Loaded with ``weights_only=True`` (tensors and primitives only: nothing in the file is executed).
-    ``trust_pickle=True`` is the explicit opt-in for a checkpoint that needs the full unpickler."""
+    ``trust_pickle=True`` is the explicit opt-in for a checkpoint that needs the full unpickler.
+    ``with_step=True`` returns ``(step or None, params)``: the trainer stores its step beside the pipeline."""
     import torch
     p = Path(path)
     if p.stat().st_size < 1024 and p.read_bytes().startswith(b"version https://git-lfs"):
         raise FileNotFoundError(f"{path} is a Git-LFS pointer, not a checkpoint")
-    sd = torch.load(p, map_location="cpu", weights_only=not trust_pickle)
-    sd = sd.get("pipeline", sd)
+    loaded = torch.load(p, map_location="cpu", weights_only=not trust_pickle)
+    sd = loaded.get("pipeline", loaded)
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
     out = {}
     for f in CKPT_FIELDS:
         key = CKPT_PREFIX + f
         if key not in sd:
             raise KeyError(f"{path}: {key} not in checkpoint")
         out[f] = sd[key].detach().float().numpy()
+    if with_step:
+        step = loaded.get("step") if isinstance(loaded, dict) else None
+        return (int(step) if step is not None else None), out
     return out
 
 

@@ -11,7 +11,7 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     r = Rasterizer(0)
     r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
     L = _capi.lib()
-    out = (ctypes.c_uint64 * 12)()
+    out = (ctypes.c_uint64 * 16)()
     r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
     L.sas_debug_counters(out, 1)
     r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
@@ -28,3 +28,4 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     print(f"  slots of a group that had entirely terminated: {gdead} ({gdead/max(trips*8,1):.2f}); slots of a live group without a lane passing the alpha test, sentinels included: {nopass} ({nopass/max(trips*8,1):.2f})")
     wait_c, loop_c = int(out[6]), int(out[7])
     print(f"  wave cycles inside the trips {loop_c/1e6:.1f} M, waiting at the batch barrier for the slowest wave {wait_c/1e6:.1f} M ({wait_c/max(loop_c,1):.2f} of the trip time)")
+    print(f"  staged entries with an empty block mask (reach no 4x4 block of their tile): {int(out[12])} of {int(out[13])} ({int(out[12])/max(int(out[13]),1):.3f})")
