@@ -53,7 +53,8 @@ typedef enum {
 #define SAS_TIME_TILES 32u    /* HIP events around the tile kernel only (SAS_T_BLEND); frames still pipeline */
 #define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */
 
-/* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING) */
+/* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING).  SAS_T_SCAN reads ~0:
+ * the offsets scan is the tail of the projection kernel (its last workgroup), not a launch of its own. */
 enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path only */,
        SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* depth fill */,
        SAS_T_TOTAL, SAS_T_COUNT };
@@ -62,7 +63,8 @@ enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path onl
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
        SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */,
-       SAS_S_QUAD_LAYOUT /* 1: the frame's tile kernel ran in its quad layout (four workgroups per tile) */, SAS_S_COUNT };
+       SAS_S_QUAD_LAYOUT /* 1: the frame's tile kernel ran in its quad layout (four workgroups per tile) */,
+       SAS_S_LAUNCH_VIEWS /* views that shared the frame's launches (1, or the size of its launch group) */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);
@@ -86,8 +88,29 @@ int sas_scene_upload(sas_ctx *ctx, int64_t n, const float *means, const float *q
                      const uint8_t *group_id, int n_groups);
 
 /* Per-group rigid poses, [n_groups,12] row-major (R|t), host pointer.  Serves the per-step
- * `splat_links_handler[i].wxyz/.position = ...` assignments (splat_handler.py:283-288). */
+ * `splat_links_handler[i].wxyz/.position = ...` assignments (splat_handler.py:283-288).
+ * The poses apply to the frames submitted AFTER the call: every frame carries a snapshot of the poses it was
+ * submitted with, so frames in flight (SAS_ASYNC) are neither disturbed nor waited for. */
 int sas_set_group_poses(sas_ctx *ctx, int n_groups, const float *Rt);
+
+/*
+ * The per-link pose algebra of SplatHandler.draw_handler (splat_handler.py:239-288) inside the library, float64:
+ *   R_k = Ri Rm_k Rfk_k^T Ri^T,   t_k = ti - R_k ti + s Ri (tm_k - Rm_k Rfk_k^T tfk_k),   tm_k = p_msg_k + weld,
+ * with Rm_k the rotation of the message quaternion; the rotation is rounded through a unit quaternion, as the
+ * reference's handles store one (handle.wxyz = ..., :283-288).
+ * sas_set_link_constants, once per scene (after sas_scene_upload, which forgets them): the ICP similarity (scale s,
+ *   rotation Ri [9], translation ti [3]: splat_handler.py:66-83), per link k the forward kinematics of its visual mesh
+ *   at mask time (Rfk [n_links,9], tfk [n_links,3]: :147-200), the weld translation (:229; NULL = 0) and the splat
+ *   group each link drives (NULL: group k).
+ * sas_set_link_poses, per env step: the first k_links links' message poses (q_msg [k,4] wxyz any norm, p_msg [k,3])
+ *   become the poses of their groups (the other groups keep theirs), exactly as sas_set_group_poses would set them;
+ *   Rt_out (or NULL) receives all current group poses [n_groups,12].
+ * sas_get_group_poses: the current poses.
+ */
+int sas_set_link_constants(sas_ctx *ctx, int n_links, double scale, const double *Ri, const double *ti, const double *Rfk,
+                           const double *tfk, const double *weld, const int *group);
+int sas_set_link_poses(sas_ctx *ctx, int k_links, const double *q_msg, const double *p_msg, float *Rt_out);
+int sas_get_group_poses(sas_ctx *ctx, int n_groups, float *Rt);
 
 /*
  * Render one view.  Serves get_outputs_for_camera (Door A) and get_render (Door B).
@@ -123,10 +146,11 @@ int sas_render_rgbd(sas_ctx *ctx, const float viewmat[16], const float K[9], int
  * Render n_views views of the same size in one call.  Serves the per-camera loops of
  * SplatHandler.render / SplatEnvWrapper.render (splat_handler.py:337-345, splat_env_wrapper.py:147-158).
  *   viewmats [n_views,16], Ks [n_views,9] host arrays; outputs are [n_views,H,W,...] device arrays
- *   (any may be NULL).  The views go through the frame slots back to back (consecutive views overlap on
- * the GPU; for scenes of >= 0.5 M Gaussians two views share one projection pass over the scene); the call
- * returns when all are complete unless SAS_ASYNC is given (then see SAS_ASYNC: views complete in order
- * inside later calls).
+ *   (any may be NULL).  Scenes of >= 0.5 M Gaussians: the views go through the frame slots two at a time, a pair
+ * sharing one projection pass over the scene, consecutive pairs overlapping on the GPU.  Smaller scenes: launch
+ * groups of (by default) two views that share every launch -- one projection, one scatter, one tile kernel with the
+ * views interleaved in dispatch order.  The call returns when all views are complete unless SAS_ASYNC is given (then
+ * see SAS_ASYNC: views complete in order inside later calls).
  */
 int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                      const float *background, unsigned flags, float *rgb, float *alpha, float *depth,
@@ -142,6 +166,20 @@ int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const flo
  */
 int sas_render_batch_host(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                           const float *background, unsigned flags, uint8_t *rgb8_host, void *stream);
+
+/*
+ * sas_render_batch / sas_render_batch_host with PER-VIEW pose sets: view v is rendered with the group poses
+ * Rt[pose_set[v]] ([n_sets, n_groups, 12] row-major (R|t), host).  Serves vectorised Gym rollouts -- E envs, each with
+ * its own link poses, C cameras per env (splat_env_wrapper.py:121-159 poses the scene per env step): one call renders
+ * all E*C views, nothing drains between envs, and views of different envs may share a launch group.  The context's
+ * current poses (sas_set_group_poses) are not changed.
+ */
+int sas_render_batch_posed(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, const int *pose_set,
+                           int n_sets, const float *Rt, int width, int height, const float *background, unsigned flags,
+                           float *rgb, float *alpha, float *depth, uint8_t *rgb8, void *stream);
+int sas_render_batch_host_posed(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, const int *pose_set,
+                                int n_sets, const float *Rt, int width, int height, const float *background,
+                                unsigned flags, uint8_t *rgb8_host, void *stream);
 
 /* Complete every SAS_ASYNC frame in flight: synchronise with each, and where its intersection buffer
  * overflowed grow it and render the frame again. */

@@ -23,11 +23,11 @@ SAS_FULL_SORT = 16
 SAS_TIME_TILES = 32
 
 STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "tail", "total")
-STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles", "quad_layout")
+STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles", "quad_layout", "launch_views")
 
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (
-    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_render_batch_host", "sas_wait", "sas_frames_completed",
+    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_set_link_constants", "sas_set_link_poses", "sas_get_group_poses", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_render_batch_host", "sas_render_batch_posed", "sas_render_batch_host_posed", "sas_wait", "sas_frames_completed",
     "sas_last_error", "sas_stage_times", "sas_stage_time_means", "sas_frame_stats", "sas_read_projection", "sas_read_tile_lists",
     "sas_version",
 )
@@ -54,10 +54,15 @@ def lib() -> ctypes.CDLL:
     L.sas_destroy.argtypes = [vp]
     L.sas_scene_upload.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci]
     L.sas_set_group_poses.argtypes = [vp, ci, vp]
+    L.sas_set_link_constants.argtypes = [vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp]
+    L.sas_set_link_poses.argtypes = [vp, ci, vp, vp, vp]
+    L.sas_get_group_poses.argtypes = [vp, ci, vp]
     L.sas_render.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
     L.sas_render_rgbd.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp, vp, vp]
     L.sas_render_batch.argtypes = [vp, ci, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
     L.sas_render_batch_host.argtypes = [vp, ci, vp, vp, ci, ci, vp, cu, vp, vp]
+    L.sas_render_batch_posed.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
+    L.sas_render_batch_host_posed.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, vp, cu, vp, vp]
     L.sas_wait.argtypes = [vp]
     L.sas_frames_completed.argtypes = [vp, vp, vp]
     L.sas_last_error.argtypes = [vp]

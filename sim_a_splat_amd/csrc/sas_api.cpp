@@ -41,10 +41,11 @@ struct RenderArgs {
 
 }  // namespace
 
-// Per-frame scratch.  Every slot owns one, so two frames can be on the GPU at the same time.
+// Per-frame scratch.  Every slot owns one, so several frames can be on the GPU at the same time.
 struct Scratch {
     DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
     long long cap = 0;
+    bool counters_zero = false;   // the counter block is known to be all zero (SasFrame invariant)
 };
 
 // One in-flight frame.  Each slot has its own internal stream (plus two side streams for the
@@ -52,40 +53,50 @@ struct Scratch {
 // parallelism to fill 256 CUs (a few thousand tiles), so consecutive frames overlap on the chip.
 // A frame writes its output buffers only after everything the caller had enqueued on `stream` at the
 // time of sas_render (its projection and binning, which touch only the scene and the slot's scratch,
-// do not wait for the caller); the caller's stream is made to wait for frame i when frame i+1 is
-// submitted (or in sas_wait), which keeps frames in flight.
+// do not wait for the caller); the caller's stream is made to wait for frame i when it is complete.
+// A frame is: [group poses: one small upload kernel] projection (+ scan in its tail) -> scatter -> tile kernel
+// [-> depth tail] [-> host copy].  Parameters travel in the kernels' argument segments, the counters are left
+// zeroed by the tile kernel, the statistics reach the host through pinned words the projection's tail writes:
+// no memset, no upload and no read-back copy around a frame.
 struct Slot {
     RenderArgs args;
     hipStream_t fs = nullptr;
     SasSortStreams sort_streams{};
     hipEvent_t start = nullptr, done = nullptr;
     hipEvent_t pair_ev = nullptr;   // leader of a view pair: both projections are done
-    hipEvent_t gpu_done = nullptr;  // the frame's last kernel is done (gate of later frames; `done` also covers the stats read-back)
     hipEvent_t ev[SAS_T_COUNT + 1] = {};
-    unsigned *stats_host = nullptr;  // pinned, 8 words
+    unsigned *stats_host = nullptr;  // pinned, 8 words, written by the projection's tail (SasFrame::stats_host)
+    float *poses_host = nullptr;     // pinned [256 * 12]: the group poses this slot's frame was submitted with
+    DevBuf poses_dev;                // ... and their device copy, uploaded in front of the projection
     Scratch scr;
     SasCam cam{};
+    SasParams params{};
     bool busy = false, timed = false, timed_tiles = false;
     bool quad = false;   // the frame's tile kernel was launched in its quad layout
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
-    // per-frame parameter block (pinned host mirror + device copy)
-    SasParams *params_host = nullptr;
-    DevBuf params_dev;
 };
 
 constexpr int kMaxSlots = 8;
+
+// Constants of the per-link pose algebra (sas_set_link_constants), float64.
+struct LinkConsts {
+    int n = 0;
+    double scale = 1.0, Ri[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ti[3] = {0, 0, 0}, weld[3] = {0, 0, 0};
+    std::vector<double> Rfk, tfk;   // [n,9], [n,3]
+    std::vector<int> group;         // [n] splat group driven by link k
+};
 
 struct sas_ctx {
     int device = 0;
     std::string err;
     // scene
-    DevBuf g0, g1, g2, col, groups, perm;
+    DevBuf g0, g1, g2, col, perm;
     DevBuf host_stage;   // device staging of sas_render_batch_host's uint8 frames
     std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
-    std::vector<float> group_host;
-    float *groups_pinned = nullptr;   // [256 * 12] pinned staging of the group poses, re-read by every frame
+    std::vector<float> group_host;    // [n_groups * 12] current poses: what a frame submitted now is rendered with
+    LinkConsts links;
     // frames
     Slot slots[kMaxSlots];
     int n_slots = 4;     // frames that may be enqueued (SAS_SLOTS=1..8; 6 and 8 are slower)
@@ -94,9 +105,6 @@ struct sas_ctx {
     int last_slot = 0;   // most recently enqueued (parity hooks)
     hipStream_t stream = nullptr;   // caller's stream of the in-flight frames
     bool has_frame = false;
-    // Optional cap on the frames that may EXECUTE at once (< n_slots): the extra frames are then queued
-    // on the GPU behind the last kernel of the frame run_depth back.
-    int run_depth = 0;   // SAS_RUN_DEPTH; 0: every enqueued frame may execute (best measured: 4 slots, ungated)
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
@@ -110,12 +118,13 @@ struct sas_ctx {
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
-    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     double stage_sum[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int64_t stage_frames = 0;
 };
+
 
 namespace {
 
@@ -236,31 +245,35 @@ void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
     c.lim_y_neg = fmaf(0.3f, tan_fovy, c.cy / c.fy);
 }
 
-SasFrame frame_of(sas_ctx *c, Scratch &q, int tiles)
+SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
 {
+    Scratch &q = sl.scr;
     SasFrame f{};
     f.rec = (float4 *)q.rec.p;
     f.info = (uint4 *)q.info.p;
-    // counters block: [stats 8 words][tile_count tiles+1]   (zeroed every frame by one memset)
-    f.stats = (unsigned *)q.counters.p;
-    f.tile_count = (int *)q.counters.p + 8;
+    // counters block: [tickets][8 device counters][tile_count tiles+1, zero padded]   (left zeroed by every frame)
+    f.tickets = (unsigned *)q.counters.p;
+    f.stats = (unsigned *)q.counters.p + SAS_TICKET_INTS;
+    f.stats_host = sl.stats_host;
+    f.tile_count = (int *)q.counters.p + SAS_TICKET_INTS + 8;
+    const size_t ts = sas_tile_stride(tiles);
     f.tile_offset = (int *)q.tilebuf.p;
-    f.tile_cursor = (int *)q.tilebuf.p + (tiles + 1);
-    f.tile_order = (int *)q.tilebuf.p + (2 * tiles + 1);
-    f.sort_class = (int *)q.tilebuf.p + (3 * tiles + 1);
+    f.tile_cursor = (int *)q.tilebuf.p + ts;
+    f.tile_order = (int *)q.tilebuf.p + 2 * ts;
+    f.sort_class = (int *)q.tilebuf.p + 3 * ts;
     f.keys = (unsigned long long *)q.keys.p;
     f.sorted_ids = (int *)q.ids.p;
     f.cap = q.cap;
     f.wg_vis = (int *)q.wgvis.p;
     f.tile_max = (unsigned *)q.tilemax.p;
-    f.n_wg = (int)((c->scene.n + 255) / 256);
+    f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
+    f.n_wg = (int)std::max<int64_t>(1, (c->scene.n + 255) / 256);
     f.n_tiles = tiles;
     return f;
 }
 
-// Roles of a slot in a view pair (sas_render_batch): the LEADER's stream uploads both parameter
-// blocks, clears both counter blocks and runs one two-view projection; the FOLLOWER's stream waits
-// for it and continues with its own binning and tiles.
+// Roles of a slot in a view pair (sas_render_batch): the LEADER's stream runs one two-view projection (whose tail
+// scans both views' counts); the FOLLOWER's stream waits for it and continues with its own binning and tiles.
 enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 
 // quad layout for views of `launch_tiles` tiles each?  By the view's own size: counting the frames in
@@ -271,12 +284,6 @@ bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags)
 {
     if ((flags & SAS_FULL_SORT) || !sas_tiles_lazy_quad_ok((flags & SAS_FAST_EXP) != 0)) return false;
     return c->quad_mode < 0 ? launch_tiles <= c->quad_max_tiles : c->quad_mode != 0;
-}
-
-size_t counter_bytes(int tiles)
-{
-    const size_t cbytes = sizeof(int) * (size_t)(8 + tiles + 1);
-    return (cbytes + 15) & ~(size_t)15;
 }
 
 // Can a kernel store to this host address (pinned / registered memory)?  Asked on every call: remembering the
@@ -290,117 +297,25 @@ bool kernel_can_write_host(sas_ctx *c, const void *p)
     return ok;
 }
 
-// what the prologue / epilogue kernels of a frame (or of the n frames of a pair / launch group) touch
-SasFrameIo frame_io(sas_ctx *c, Slot *const *sl, int n)
+// Group poses of the n frames (one launch): each slot's snapshot goes to its own device block, so frames in flight
+// may carry different poses (vectorised envs, a pose update per Gym step) and nothing drains between them.
+int enqueue_poses(sas_ctx *c, Slot *const *sl, int n, hipStream_t st)
 {
-    SasFrameIo io{};
-    io.nv = n;
+    if (c->scene.n_groups <= 0) return SAS_OK;
+    SasPoseUpload u{};
+    u.nv = n;
     for (int k = 0; k < n; ++k) {
-        const int tiles = sl[k]->cam.tw * sl[k]->cam.th;
-        io.params_dev[k] = (SasParams *)sl[k]->params_dev.p;
-        io.params_host[k] = sl[k]->params_host;
-        io.counters[k] = (unsigned *)sl[k]->scr.counters.p;
-        io.counter_words[k] = (int)(counter_bytes(tiles) / sizeof(unsigned));
-        io.stats_host[k] = sl[k]->stats_host;
+        u.dst[k] = (float *)sl[k]->poses_dev.p;
+        u.src_host[k] = sl[k]->poses_host;
+        u.floats[k] = 12 * c->scene.n_groups;
     }
-    io.want_stats = 1;
-    if (c->scene.group_Rt) {   // frames in flight at the same time carry the same poses: set_group_poses drains first
-        io.groups_dev = (float *)c->groups.p;
-        io.groups_host = c->groups_pinned;
-        io.group_floats = 12 * c->scene.n_groups;
-    }
-    return io;
-}
-
-// Uploads and clears that depend on nothing on the GPU: the slot's parameter block and counters (for
-// a pair leader also the follower's) and the group poses.  Issued BEFORE the stream waits for the
-// caller's stream and for the frame two back, so that it runs while the previous frames are still compositing
-// instead of in front of the projection.  For a view pair, a launch group or a scene with group poses ONE kernel
-// (k_frame_prologue) reads the pinned host blocks itself: as runtime blits these were three to five ~6 us
-// commands one after the other (Gym-camera step 208 -> 193 us, view pairs +1.3 %).
-int enqueue_prologue(sas_ctx *c, Slot &sl, hipStream_t st, int role, Slot *partner)
-{
-    if (role == ROLE_FOLLOWER) return SAS_OK;
-    if (role == ROLE_SINGLE && !c->scene.group_Rt) {
-        // two blits: the copy engines take them beside the compute queues, which measured 2-3 % better for single
-        // views in flight than a kernel (and the same for a blocking frame)
-        const int tiles = sl.cam.tw * sl.cam.th;
-        HIP_TRY(c, hipMemcpyAsync(sl.params_dev.p, sl.params_host, sizeof(SasParams), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemsetAsync(sl.scr.counters.p, 0, counter_bytes(tiles), st));
-        return SAS_OK;
-    }
-    Slot *mem[2] = {&sl, partner};
-    sas_launch_frame_prologue(st, frame_io(c, mem, role == ROLE_LEADER ? 2 : 1));
+    sas_launch_pose_upload(st, u);
     return SAS_OK;
 }
 
-// The frame's work on stream `st`: (prologue,) the five stages, stats read-back.
-int enqueue_body(sas_ctx *c, Slot &sl, hipStream_t st, bool timing, int role, Slot *partner, bool with_prologue,
-                 bool late_start_wait)
-{
-    const RenderArgs &a = sl.args;
-    const SasCam &cam = sl.cam;
-    const int tiles = cam.tw * cam.th;
-    Scratch &q = sl.scr;
-    SasFrame f = frame_of(c, q, tiles);
-    const SasParams *P = (const SasParams *)sl.params_dev.p;
-    if (with_prologue) {
-        const int rc = enqueue_prologue(c, sl, st, role, partner);
-        if (rc) return rc;
-    }
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
-    if (role == ROLE_LEADER) {
-        const int ptiles = partner->cam.tw * partner->cam.th;
-        sas_launch_project2(st, c->scene, P, f, (const SasParams *)partner->params_dev.p, frame_of(c, partner->scr, ptiles));
-        HIP_TRY(c, hipEventRecord(sl.pair_ev, st));
-    } else if (role == ROLE_SINGLE) {
-        sas_launch_project(st, c->scene, P, f);
-    }
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[1], st));
-    sas_launch_scan(st, tiles, f);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[2], st));
-    sas_launch_scatter(st, c->scene, cam.tw, f);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
-    const bool full = (a.flags & SAS_FULL_SORT) != 0;
-    // The caller's stream matters to a frame only through the output buffers (a consumer of an earlier
-    // frame may still be reading the buffer this frame will overwrite): everything up to here touches
-    // only the scene and the slot's scratch, so the wait for the caller's work sits here, where it has
-    // long been satisfied, and not in front of the projection (where it chained every frame behind the
-    // stats read-back of the frame two back through two extra cross-queue event hops).
-    if (late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
-    if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
-    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
-    const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
-    const bool quad = !full && use_quad(c, tiles, a.flags);
-    sl.quad = quad;
-    if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
-    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill, quad,
-                               ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
-    const bool pts = a.depth && (a.points || a.mask);
-    if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
-    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
-    if (a.rgb8_host && a.rgb8) {   // frame wanted on the host: by a kernel when the destination is pinned (no copy-engine hop)
-        const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
-        if (kernel_can_write_host(c, a.rgb8_host)) {
-            SasFrameIo io{};
-            io.nv = 1;
-            io.host_src[0] = a.rgb8;
-            io.host_dst[0] = a.rgb8_host;
-            io.host_bytes = fb;
-            sas_launch_frame_epilogue(st, io);
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(a.rgb8_host, a.rgb8, fb, hipMemcpyDeviceToHost, st));
-        }
-    }
-    HIP_TRY(c, hipEventRecord(sl.gpu_done, st));
-    HIP_TRY(c, hipMemcpyAsync(sl.stats_host, q.counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    return SAS_OK;
-}
-
-// Camera constants, scratch sizes and the host copy of the parameter block of the slot's frame.
-int prepare_frame(sas_ctx *c, Slot &sl)
+// Camera constants, scratch sizes and the parameter block of the slot's frame.  `init_st`: the stream the frame's
+// projection will run on (the slot's own, or its pair / group leader's): a new counter block is cleared there.
+int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
 {
     const RenderArgs &a = sl.args;
     make_cam(a.viewmat, a.K, a.W, a.H, sl.cam);
@@ -418,15 +333,23 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     }
     if ((rc = ensure(c, q.rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
-    if ((rc = ensure(c, q.tilebuf, sizeof(int) * (size_t)(4 * tiles + 16)))) return rc;
-    if ((rc = ensure(c, q.counters, counter_bytes(tiles)))) return rc;
+    if ((rc = ensure(c, q.tilebuf, sizeof(int) * (3 * sas_tile_stride(tiles) + 16)))) return rc;
+    {
+        const size_t cb = sizeof(int) * sas_counter_ints(tiles);
+        if (cb > q.counters.bytes || !q.counters.p) q.counters_zero = false;
+        if ((rc = ensure(c, q.counters, cb))) return rc;
+        if (!q.counters_zero) {   // new block, or a frame that failed half way: zero all of it once, on the slot's stream
+            HIP_TRY(c, hipMemsetAsync(q.counters.p, 0, q.counters.bytes, init_st));
+            q.counters_zero = true;
+        }
+    }
     if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
     if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * 4 * (size_t)tiles))) return rc;   // x 4: one slot per quadrant in the quad layout
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
-    if ((rc = ensure(c, sl.params_dev, sizeof(SasParams)))) return rc;
+    if (c->scene.n_groups > 0 && (rc = ensure(c, sl.poses_dev, sizeof(float) * 12 * 256))) return rc;
 
-    SasParams &hp = *sl.params_host;
+    SasParams &hp = sl.params;
     hp.cam = cam;
     hp.out.rgb = a.rgb; hp.out.alpha = a.alpha; hp.out.depth = a.depth; hp.out.rgb8 = a.rgb8;
     hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
@@ -436,37 +359,75 @@ int prepare_frame(sas_ctx *c, Slot &sl)
     return SAS_OK;
 }
 
-// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).  Every frame is
-// launched eagerly (~25 runtime calls, hidden by the frames in flight).  The two frames of a view pair
-// (role, partner; both prepared by the caller) share the leader's projection.
+// Enqueue the slot's frame on its internal stream (the slot must be idle on the GPU).  The two frames of a view
+// pair (role, partner; both prepared by the caller) share the leader's projection.
 int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = nullptr)
 {
     const RenderArgs &a = sl.args;
     int rc;
-    if (role == ROLE_SINGLE && (rc = prepare_frame(c, sl))) return rc;
-
+    if (role == ROLE_SINGLE && (rc = prepare_frame(c, sl, sl.fs))) return rc;
     const bool timing = (a.flags & SAS_TIMING) != 0;
+    const bool full = (a.flags & SAS_FULL_SORT) != 0;
+    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0 && !timing && !full;
     hipStream_t st = sl.fs;
-    const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
-    // untimed frames: the uploads go first, ahead of every wait (the slot's own previous frame is complete)
-    const bool early_prologue = !timing;
-    if (early_prologue && (rc = enqueue_prologue(c, sl, st, role, partner))) return rc;
-    // after whatever the caller has enqueued on its stream so far: timed frames as a whole, the others
-    // from the tile kernel on (enqueue_body)
+    const SasCam &cam = sl.cam;
+    const int tiles = cam.tw * cam.th;
+    const SasFrame f = frame_of(c, sl, tiles);
+    const SasParams &P = sl.params;
+
+    // after whatever the caller has enqueued on its stream so far: timed frames as a whole, the others from the
+    // tile kernel on (the first thing that writes an output buffer; everything before touches only the scene and
+    // the slot's scratch)
     HIP_TRY(c, hipEventRecord(sl.start, a.stream));
-    const bool late_start_wait = early_prologue;
-    if (!late_start_wait) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
-    if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
-    if (c->run_depth > 0 && c->run_depth < c->n_slots) {
-        const int me = (int)(&sl - c->slots);
-        Slot &gate = c->slots[(me + c->n_slots - c->run_depth) % c->n_slots];   // frame j - run_depth
-        HIP_TRY(c, hipStreamWaitEvent(st, gate.gpu_done, 0));
+    if (timing) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    if (role != ROLE_FOLLOWER) {
+        Slot *mem[1] = {&sl};
+        if ((rc = enqueue_poses(c, mem, 1, st))) return rc;   // a pair shares its poses: the leader's block serves both views
     }
-    rc = enqueue_body(c, sl, st, timing, role, partner, !early_prologue, late_start_wait);
-    if (rc) return rc;
+    if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
+    if (role == ROLE_LEADER) {
+        const int ptiles = partner->cam.tw * partner->cam.th;
+        sas_launch_project2(st, c->scene, P, f, partner->params, frame_of(c, *partner, ptiles));
+        HIP_TRY(c, hipEventRecord(sl.pair_ev, st));
+    } else if (role == ROLE_SINGLE) {
+        sas_launch_project(st, c->scene, P, f);
+    }
+    if (timing) {
+        HIP_TRY(c, hipEventRecord(sl.ev[1], st));
+        HIP_TRY(c, hipEventRecord(sl.ev[2], st));   // SAS_T_SCAN: the scan is the projection's tail
+    }
+    sas_launch_scatter(st, c->scene, cam.tw, f);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
+    if (!timing) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
+    const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
+    const bool quad = !full && use_quad(c, tiles, a.flags);
+    sl.quad = quad;
+    if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
+    else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill, quad,
+                               ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
+    const bool pts = a.depth && (a.points || a.mask);
+    if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
+    if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
+    if (a.rgb8_host && a.rgb8) {   // frame wanted on the host: by a kernel when the destination is pinned (no copy-engine hop)
+        const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
+        if (kernel_can_write_host(c, a.rgb8_host)) {
+            SasHostCopy h{};
+            h.nv = 1;
+            h.src[0] = a.rgb8;
+            h.dst[0] = a.rgb8_host;
+            h.bytes = fb;
+            sas_launch_host_copy(st, h);
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(a.rgb8_host, a.rgb8, fb, hipMemcpyDeviceToHost, st));
+        }
+    }
     HIP_TRY(c, hipGetLastError());
     sl.timed = timing;
-    sl.timed_tiles = ttiles && !timing && !(a.flags & SAS_FULL_SORT);
+    sl.timed_tiles = ttiles;
     HIP_TRY(c, hipEventRecord(sl.done, st));
     sl.busy = true;
     c->has_frame = true;
@@ -474,31 +435,28 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
 }
 
 // Enqueue n same-sized views (consecutive idle slots sl[0..n-1], args filled) as ONE launch group on the leader's
-// stream: per-view parameter / counter uploads, then one projection, one scan, one scatter and one tile launch
-// with grid.y = view.  A Gym step's cameras on a small scene are launch-bound (~25 runtime calls and four
-// 10-30 us kernels per camera); the group needs 3 n + 10 calls and its kernels fill more of the chip.
+// stream: one pose upload, one projection, one scatter and one tile launch with grid.y = view.  A Gym step's cameras
+// on a small scene are launch-bound; the group's kernels also fill more of the chip.
 int enqueue_group(sas_ctx *c, Slot **sl, int n)
 {
     int rc;
-    for (int k = 0; k < n; ++k)
-        if ((rc = prepare_frame(c, *sl[k]))) return rc;
     Slot &ld = *sl[0];
     hipStream_t st = ld.fs;
+    for (int k = 0; k < n; ++k)
+        if ((rc = prepare_frame(c, *sl[k], st))) return rc;
     const RenderArgs &a = ld.args;
     const int tiles = ld.cam.tw * ld.cam.th;
     SasMulti mf{};
     mf.nv = n;
     for (int k = 0; k < n; ++k) {
-        mf.f[k] = frame_of(c, sl[k]->scr, tiles);
-        mf.P[k] = (const SasParams *)sl[k]->params_dev.p;
+        mf.f[k] = frame_of(c, *sl[k], tiles);
+        mf.P[k] = sl[k]->params;
     }
-    const SasFrameIo io = frame_io(c, sl, n);
-    sas_launch_frame_prologue(st, io);
+    if ((rc = enqueue_poses(c, sl, n, st))) return rc;
     HIP_TRY(c, hipEventRecord(ld.start, a.stream));
     sas_launch_project_multi(st, c->scene, mf);
-    sas_launch_scan_multi(st, tiles, mf);
     sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);
-    HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel (enqueue_body)
+    HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
@@ -512,17 +470,19 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         const bool pts = ak.depth && (ak.points || ak.mask);
         if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, mf.P[k], mf.f[k], fill, pts);
     }
-    SasFrameIo ioe = io;
-    {   // frames wanted on the host (sas_render_batch_host): by the epilogue kernel when the destination is pinned
+    {   // frames wanted on the host (sas_render_batch_host): by a kernel when the destination is pinned
         const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
         bool any = false;
         for (int k = 0; k < n; ++k) any = any || (sl[k]->args.rgb8_host && sl[k]->args.rgb8);
         if (any && kernel_can_write_host(c, a.rgb8_host ? a.rgb8_host : sl[n - 1]->args.rgb8_host)) {
+            SasHostCopy h{};
+            h.nv = n;
             for (int k = 0; k < n; ++k) {
-                ioe.host_src[k] = sl[k]->args.rgb8_host ? sl[k]->args.rgb8 : nullptr;
-                ioe.host_dst[k] = sl[k]->args.rgb8_host;
+                h.src[k] = sl[k]->args.rgb8_host ? sl[k]->args.rgb8 : nullptr;
+                h.dst[k] = sl[k]->args.rgb8_host;
             }
-            ioe.host_bytes = fb;
+            h.bytes = fb;
+            sas_launch_host_copy(st, h);
         } else if (any) {
             for (int k = 0; k < n; ++k) {
                 const RenderArgs &ak = sl[k]->args;
@@ -530,8 +490,6 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
             }
         }
     }
-    HIP_TRY(c, hipEventRecord(ld.gpu_done, st));
-    sas_launch_frame_epilogue(st, ioe);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ld.done, st));
     for (int k = 0; k < n; ++k) {
@@ -543,6 +501,13 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     ld.timed_tiles = ttiles;
     c->has_frame = true;
     return SAS_OK;
+}
+
+// After a failure somewhere inside a frame's enqueue the counters can no longer be assumed zero.
+void mark_dirty(sas_ctx *c)
+{
+    (void)hipDeviceSynchronize();
+    for (Slot &sl : c->slots) sl.scr.counters_zero = false;
 }
 
 // Verify the oldest in-flight frame; on overflow grow its intersection buffer and render it again.
@@ -557,7 +522,7 @@ int complete_oldest(sas_ctx *c)
         HIP_TRY(c, hipEventSynchronize(sl.done));
         bool overflow = false;
         for (int k = 0; k < g; ++k) {
-            const unsigned *s = mem[k]->stats_host;
+            const volatile unsigned *s = mem[k]->stats_host;   // written by the projection's tail (+ the tile kernel's [6])
             c->stats[SAS_S_NVISIBLE] = s[0];
             c->stats[SAS_S_NISECT] = s[1];
             c->stats[SAS_S_MAX_TILE_LEN] = s[4];
@@ -566,6 +531,7 @@ int complete_oldest(sas_ctx *c)
             c->stats[SAS_S_WINDOW_MISSES] = s[5];
             c->stats[SAS_S_FALLBACK_TILES] = s[6];
             c->stats[SAS_S_QUAD_LAYOUT] = mem[k]->quad ? 1 : 0;
+            c->stats[SAS_S_LAUNCH_VIEWS] = g;
             overflow = overflow || s[2] != 0;
         }
         if (sl.timed) {
@@ -596,7 +562,8 @@ int complete_oldest(sas_ctx *c)
             c->frames_completed += g;
             return SAS_OK;
         }
-        // intersection buffer too small: grow to the measured need (+25 %) and render the frame (group) again
+        // intersection buffer too small: grow to the measured need (+25 %) and render the frame (group) again,
+        // with the poses it was submitted with (the slot's snapshot)
         long long want = 0;
         for (int k = 0; k < g; ++k) {
             const long long need = (long long)mem[k]->stats_host[1];
@@ -608,7 +575,7 @@ int complete_oldest(sas_ctx *c)
             if (o.scr.cap && o.scr.cap < want && !o.busy) o.scr.cap = want;
         c->regrows++;
         int rc = g > 1 ? enqueue_group(c, mem, g) : enqueue_frame(c, sl);
-        if (rc) return rc;
+        if (rc) { mark_dirty(c); return rc; }
     }
     return fail(c, SAS_ERR_HIP, "intersection buffer kept overflowing");
 }
@@ -643,7 +610,6 @@ int sas_create(int device, sas_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= kMaxSlots) c->n_slots = v;
     }
-    if (const char *e = getenv("SAS_RUN_DEPTH")) c->run_depth = atoi(e);
     if (const char *e = getenv("SAS_PAIR")) c->pair_views = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SAS_GROUP")) {
         const int v = atoi(e);
@@ -654,15 +620,13 @@ int sas_create(int device, sas_ctx **out)
         const int v = atoi(e);
         if (v >= 0) c->quad_max_tiles = v;
     }
-    ok = ok && hipHostMalloc((void **)&c->groups_pinned, sizeof(float) * 12 * 256) == hipSuccess;
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
-        ok = ok && hipHostMalloc((void **)&sl.params_host, sizeof(SasParams)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&sl.poses_host, sizeof(float) * 12 * 256) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&sl.fs, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.start, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.pair_ev, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&sl.gpu_done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         for (auto &sd : sl.sort_streams.side) ok = ok && hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&sl.sort_streams.fork, hipEventDisableTiming) == hipSuccess;
@@ -681,7 +645,6 @@ int sas_destroy(sas_ctx *c)
 {
     if (!c) return SAS_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->groups_pinned) { (void)hipHostFree(c->groups_pinned); c->groups_pinned = nullptr; }
     for (Slot &sl : c->slots) {
         if (sl.fs) (void)hipStreamSynchronize(sl.fs);
         for (auto &sd : sl.sort_streams.side)
@@ -691,19 +654,18 @@ int sas_destroy(sas_ctx *c)
             if (e) (void)hipEventDestroy(e);
         if (sl.fs) (void)hipStreamDestroy(sl.fs);
         if (sl.stats_host) (void)hipHostFree(sl.stats_host);
-        if (sl.params_host) (void)hipHostFree(sl.params_host);
-        release(sl.params_dev);
+        if (sl.poses_host) (void)hipHostFree(sl.poses_host);
+        release(sl.poses_dev);
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.pair_ev) (void)hipEventDestroy(sl.pair_ev);
-        if (sl.gpu_done) (void)hipEventDestroy(sl.gpu_done);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
                           &sl.scr.wgvis, &sl.scr.tilemax})
             release(*b);
     }
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->groups, &c->perm, &c->host_stage}) release(*b);
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->perm, &c->host_stage}) release(*b);
     delete c;
     return SAS_OK;
 }
@@ -795,15 +757,11 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     c->scene.sh_degree = deg;
     c->scene.cov_mode = quat_mode ? 0 : 1;
     c->scene.n_groups = group_id ? n_groups : 0;
-    c->scene.group_Rt = nullptr;
     c->group_host.clear();
-    if (group_id) {
+    c->links = LinkConsts{};
+    if (group_id) {   // poses start as identity
         c->group_host.assign((size_t)12 * n_groups, 0.0f);
         for (int g = 0; g < n_groups; ++g) c->group_host[12 * g + 0] = c->group_host[12 * g + 5] = c->group_host[12 * g + 10] = 1.0f;
-        if ((rc = ensure(c, c->groups, sizeof(float) * 12 * 256))) return rc;
-        memcpy(c->groups_pinned, c->group_host.data(), sizeof(float) * 12 * n_groups);
-        HIP_TRY(c, hipMemcpy(c->groups.p, c->groups_pinned, sizeof(float) * 12 * n_groups, hipMemcpyHostToDevice));
-        c->scene.group_Rt = (const float *)c->groups.p;
     }
     for (Slot &sl : c->slots) sl.scr.cap = 0;  // re-derive the intersection capacity for the new scene
     c->has_frame = false;
@@ -817,15 +775,138 @@ int sas_set_group_poses(sas_ctx *c, int n_groups, const float *Rt)
     if (!c || !Rt) return SAS_ERR_INVALID;
     if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
     if (n_groups != c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "scene has %d groups, got %d", c->scene.n_groups, n_groups);
-    HIP_TRY(c, hipSetDevice(c->device));
-    {
-        int rc = complete_all(c);   // in-flight frames may still have to be re-rendered with the old poses
-        if (rc) return rc;
-    }
+    // Every frame carries a snapshot of the poses it was submitted with (its slot's block, uploaded in front of its
+    // projection; kept for the case that it has to be rendered again), so frames in flight are not disturbed and
+    // nothing is drained here: the new poses apply to the frames submitted from now on.
     c->group_host.assign(Rt, Rt + (size_t)12 * n_groups);
-    // No frame is in flight here.  The poses go into a pinned staging block that every frame copies
-    // to the device on its own stream, like the per-frame parameter block.
-    memcpy(c->groups_pinned, Rt, sizeof(float) * 12 * n_groups);
+    return SAS_OK;
+}
+
+// ---- per-link pose algebra (rows a8 of SURVEY.md 8a; reference: splat_handler.py:239-288) -----------------------
+// float64, the same expressions in the same order as sim_a_splat_amd/poses.py (quats_wxyz_to_matrices,
+// link_splat_poses, matrices_to_quats_wxyz) and SplatScene._sync (quaternion -> matrix -> float32): the handle of a
+// splat group stores a quaternion in the reference (handle.wxyz = ...), so the rotation goes matrix -> quaternion ->
+// matrix here as well.  Built with -ffp-contract=off like everything else: no fused multiply-adds.
+namespace {
+
+void quat_to_matrix(const double *qin, double *R)
+{
+    const double n = std::sqrt(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+    const double q[4] = {qin[0] / n, qin[1] / n, qin[2] / n, qin[3] / n};
+    double qq[4][4];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) qq[a][b] = q[a] * q[b];
+    R[0] = 1 - 2 * (qq[2][2] + qq[3][3]); R[1] = 2 * (qq[1][2] - qq[0][3]); R[2] = 2 * (qq[1][3] + qq[0][2]);
+    R[3] = 2 * (qq[1][2] + qq[0][3]); R[4] = 1 - 2 * (qq[1][1] + qq[3][3]); R[5] = 2 * (qq[2][3] - qq[0][1]);
+    R[6] = 2 * (qq[1][3] - qq[0][2]); R[7] = 2 * (qq[2][3] + qq[0][1]); R[8] = 1 - 2 * (qq[1][1] + qq[2][2]);
+}
+
+void matrix_to_quat(const double *R, double *q)
+{
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        const double s = std::sqrt(tr + 1.0) * 2;
+        q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        const double s = std::sqrt(1.0 + R[4 * i] - R[4 * j] - R[4 * k]) * 2;
+        q[0] = (R[3 * k + j] - R[3 * j + k]) / s;
+        q[1 + i] = 0.25 * s;
+        q[1 + j] = (R[3 * j + i] + R[3 * i + j]) / s;
+        q[1 + k] = (R[3 * k + i] + R[3 * i + k]) / s;
+    }
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; ++a) q[a] /= n;
+}
+
+// C = A B (3x3, row-major); tb: B transposed.  Sums left to right, as a plain triple loop does.
+void mul33(const double *A, const double *B, bool tb, double *C)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += A[3 * r + k] * (tb ? B[3 * c + k] : B[3 * k + c]);
+            C[3 * r + c] = acc;
+        }
+}
+
+}  // namespace
+
+int sas_set_link_constants(sas_ctx *c, int n_links, double scale, const double *Ri, const double *ti, const double *Rfk,
+                           const double *tfk, const double *weld, const int *group)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
+    if (n_links < 0 || n_links > c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "n_links %d out of [0, %d groups]", n_links, c->scene.n_groups);
+    if (n_links > 0 && (!Ri || !ti || !Rfk || !tfk)) return fail(c, SAS_ERR_INVALID, "Ri, ti, Rfk, tfk are required");
+    LinkConsts L;
+    L.n = n_links;
+    L.scale = scale;
+    if (n_links > 0) {
+        memcpy(L.Ri, Ri, sizeof(L.Ri));
+        memcpy(L.ti, ti, sizeof(L.ti));
+        if (weld) memcpy(L.weld, weld, sizeof(L.weld));
+        L.Rfk.assign(Rfk, Rfk + 9 * (size_t)n_links);
+        L.tfk.assign(tfk, tfk + 3 * (size_t)n_links);
+        L.group.resize((size_t)n_links);
+        for (int k = 0; k < n_links; ++k) {
+            const int g = group ? group[k] : k;
+            if (g < 0 || g >= c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "group[%d]=%d out of [0,%d)", k, g, c->scene.n_groups);
+            L.group[(size_t)k] = g;
+        }
+    }
+    c->links = L;
+    return SAS_OK;
+}
+
+int sas_set_link_poses(sas_ctx *c, int k_links, const double *q_msg, const double *p_msg, float *Rt_out)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
+    const LinkConsts &L = c->links;
+    if (k_links < 0 || k_links > L.n) return fail(c, SAS_ERR_INVALID, "%d link poses, constants for %d (sas_set_link_constants)", k_links, L.n);
+    if (k_links > 0 && (!q_msg || !p_msg)) return fail(c, SAS_ERR_INVALID, "q_msg and p_msg are required");
+    for (int k = 0; k < k_links; ++k) {
+        double Rm[9], RmF[9], T1[9], R[9], q[4], Rq[9];
+        quat_to_matrix(q_msg + 4 * k, Rm);
+        const double tm[3] = {p_msg[3 * k] + L.weld[0], p_msg[3 * k + 1] + L.weld[1], p_msg[3 * k + 2] + L.weld[2]};
+        mul33(Rm, &L.Rfk[9 * (size_t)k], true, RmF);    // Rm Rfk^T
+        mul33(L.Ri, RmF, false, T1);
+        mul33(T1, L.Ri, true, R);                        // R = Ri Rm Rfk^T Ri^T
+        // t = ti - R ti + s (tm - RmF tfk) Ri^T
+        double u[3], t[3];
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j) acc += RmF[3 * r + j] * L.tfk[3 * (size_t)k + j];
+            u[r] = L.scale * (tm[r] - acc);
+        }
+        for (int r = 0; r < 3; ++r) {
+            double rti = 0.0, uri = 0.0;
+            for (int j = 0; j < 3; ++j) rti += R[3 * r + j] * L.ti[j];
+            for (int j = 0; j < 3; ++j) uri += u[j] * L.Ri[3 * r + j];
+            t[r] = (L.ti[r] - rti) + uri;
+        }
+        matrix_to_quat(R, q);        // what the handle stores ...
+        quat_to_matrix(q, Rq);       // ... and what the scene uploads
+        float *dst = &c->group_host[12 * (size_t)L.group[(size_t)k]];
+        for (int r = 0; r < 3; ++r) {
+            for (int j = 0; j < 3; ++j) dst[4 * r + j] = (float)Rq[3 * r + j];
+            dst[4 * r + 3] = (float)t[r];
+        }
+    }
+    if (Rt_out && !c->group_host.empty()) memcpy(Rt_out, c->group_host.data(), sizeof(float) * c->group_host.size());
+    return SAS_OK;
+}
+
+int sas_get_group_poses(sas_ctx *c, int n_groups, float *Rt)
+{
+    if (!c || !Rt) return SAS_ERR_INVALID;
+    if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
+    if (n_groups != c->scene.n_groups) return fail(c, SAS_ERR_INVALID, "scene has %d groups, got %d", c->scene.n_groups, n_groups);
+    if (n_groups > 0) memcpy(Rt, c->group_host.data(), sizeof(float) * 12 * (size_t)n_groups);
     return SAS_OK;
 }
 
@@ -836,6 +917,7 @@ struct ViewCall {
     float *points;
     uint8_t *mask;
     uint8_t *rgb8_host = nullptr;
+    const float *poses = nullptr;   // [n_groups,12] group poses of THIS view (a pose set), or nullptr: the context's current poses
 };
 
 static int check_view(sas_ctx *c, const ViewCall &v, int width, int height)
@@ -865,6 +947,13 @@ static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, c
     a.valid = true;
 }
 
+// the poses the slot's frame is rendered with: the view's own set, else the context's current ones
+static void snapshot_poses(sas_ctx *c, Slot &sl, const ViewCall &v)
+{
+    if (c->scene.n_groups <= 0) return;
+    memcpy(sl.poses_host, v.poses ? v.poses : c->group_host.data(), sizeof(float) * 12 * (size_t)c->scene.n_groups);
+}
+
 // One view (n == 1), a pair of views that share one projection pass (n == 2), or -- `grouped` -- up to
 // SAS_MAX_GROUP views that share every launch (enqueue_group).
 static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int height, const float *background,
@@ -890,10 +979,11 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
     for (int k = 0; k < n; ++k) {
         sl[k] = &c->slots[(c->head + c->inflight + k) % c->n_slots];
         fill_args(sl[k]->args, views[k], width, height, background, flags, max_depth, st);
+        snapshot_poses(c, *sl[k], views[k]);
     }
     if (grouped) {
         const int rc = enqueue_group(c, sl, n);
-        if (rc) return rc;
+        if (rc) { mark_dirty(c); return rc; }
         c->inflight += n;
         c->frames_submitted += n;
         c->last_slot = (int)(sl[n - 1] - c->slots);
@@ -902,14 +992,14 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
     }
     if (n == 2) {
         for (int k = 0; k < 2; ++k) {
-            const int rc = prepare_frame(c, *sl[k]);
+            const int rc = prepare_frame(c, *sl[k], sl[0]->fs);
             if (rc) return rc;
         }
     }
     for (int k = 0; k < n; ++k) {
         const int role = n == 1 ? ROLE_SINGLE : (k == 0 ? ROLE_LEADER : ROLE_FOLLOWER);
         int rc = enqueue_frame(c, *sl[k], role, n == 2 ? sl[1 - k] : nullptr);
-        if (rc) return rc;
+        if (rc) { mark_dirty(c); return rc; }
         c->inflight++;
         c->frames_submitted++;
         c->last_slot = (int)(sl[k] - c->slots);
@@ -941,21 +1031,38 @@ int sas_render_rgbd(sas_ctx *c, const float *viewmat, const float *K, int width,
                        max_depth, stream);
 }
 
+// pose sets of a batch: view v is rendered with rows pose_sets[pose_set[v]] (each set [n_groups,12]); no sets: the
+// context's current poses for every view
+struct PoseSets {
+    const int *pose_set = nullptr;
+    int n_sets = 0;
+    const float *Rt = nullptr;
+};
+
 static int render_batch_impl(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
                              const float *background, unsigned flags, float *rgb, float *alpha, float *depth, uint8_t *rgb8,
-                             uint8_t *rgb8_host, void *stream)
+                             uint8_t *rgb8_host, void *stream, const PoseSets &ps = PoseSets())
 {
     if (!c) return SAS_ERR_INVALID;
     if (n_views < 0 || (n_views > 0 && (!viewmats || !Ks))) return fail(c, SAS_ERR_INVALID, "bad view batch");
+    if (ps.Rt) {
+        if (!c->has_scene) return fail(c, SAS_ERR_NO_SCENE, "no scene uploaded");
+        if (c->scene.n_groups <= 0) return fail(c, SAS_ERR_INVALID, "pose sets given but the scene has no splat groups");
+        if (ps.n_sets <= 0 || !ps.pose_set) return fail(c, SAS_ERR_INVALID, "pose sets need pose_set[n_views] and n_sets > 0");
+        for (int v = 0; v < n_views; ++v)
+            if (ps.pose_set[v] < 0 || ps.pose_set[v] >= ps.n_sets)
+                return fail(c, SAS_ERR_INVALID, "pose_set[%d]=%d out of [0,%d)", v, ps.pose_set[v], ps.n_sets);
+    }
     const size_t px = (size_t)width * (size_t)height;
     auto view = [&](int v) {
         ViewCall vc{viewmats + 16 * v, Ks + 9 * v, rgb ? rgb + 3 * px * v : nullptr, alpha ? alpha + px * v : nullptr,
                     depth ? depth + px * v : nullptr, rgb8 ? rgb8 + 3 * px * v : nullptr, nullptr, nullptr};
         vc.rgb8_host = rgb8_host ? rgb8_host + 3 * px * v : nullptr;
+        vc.poses = ps.Rt ? ps.Rt + (size_t)12 * c->scene.n_groups * ps.pose_set[v] : nullptr;
         return vc;
     };
     // Views go through the frame slots two at a time: one pass over the scene projects both
-    // (timed and full-sort frames keep to one view per pass).
+    // (timed and full-sort frames keep to one view per pass; so do two views of different pose sets).
     const bool want_pairs = c->pair_views < 0 ? c->scene.n >= sas_ctx::kPairMinGaussians : c->pair_views != 0;
     const bool pair = want_pairs && c->n_slots >= 2 && !(flags & (SAS_TIMING | SAS_FULL_SORT));
     // small scenes (not paired): launch groups, by default half of the slots each so that two can be in flight
@@ -972,8 +1079,9 @@ static int render_batch_impl(sas_ctx *c, int n_views, const float *viewmats, con
             v += n;
             continue;
         }
-        const int n = (pair && v + 1 < n_views) ? 2 : 1;
-        const ViewCall vc[2] = {view(v), view(n == 2 ? v + 1 : v)};
+        const ViewCall v0 = view(v);
+        const int n = (pair && v + 1 < n_views && view(v + 1).poses == v0.poses) ? 2 : 1;
+        const ViewCall vc[2] = {v0, view(n == 2 ? v + 1 : v)};
         int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream);
         if (rc) return rc;
         v += n;
@@ -989,8 +1097,18 @@ int sas_render_batch(sas_ctx *c, int n_views, const float *viewmats, const float
     return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb, alpha, depth, rgb8, nullptr, stream);
 }
 
-int sas_render_batch_host(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
-                          const float *background, unsigned flags, uint8_t *rgb8_host, void *stream)
+int sas_render_batch_posed(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, const int *pose_set, int n_sets,
+                           const float *Rt, int width, int height, const float *background, unsigned flags, float *rgb,
+                           float *alpha, float *depth, uint8_t *rgb8, void *stream)
+{
+    PoseSets ps;
+    ps.pose_set = pose_set; ps.n_sets = n_sets; ps.Rt = Rt;
+    if (!Rt) return fail(c, SAS_ERR_INVALID, "sas_render_batch_posed: Rt is required");
+    return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb, alpha, depth, rgb8, nullptr, stream, ps);
+}
+
+static int render_batch_host_impl(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                                  const float *background, unsigned flags, uint8_t *rgb8_host, void *stream, const PoseSets &ps)
 {
     if (!c) return SAS_ERR_INVALID;
     if (!rgb8_host || (flags & SAS_ASYNC)) return fail(c, SAS_ERR_INVALID, "sas_render_batch_host: host buffer required, blocking only");
@@ -1004,7 +1122,23 @@ int sas_render_batch_host(sas_ctx *c, int n_views, const float *viewmats, const 
     const int rc = ensure(c, c->host_stage, 3 * (size_t)width * (size_t)height * (size_t)n_views);
     if (rc) return rc;
     return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, nullptr, nullptr, nullptr,
-                             (uint8_t *)c->host_stage.p, rgb8_host, stream);
+                             (uint8_t *)c->host_stage.p, rgb8_host, stream, ps);
+}
+
+int sas_render_batch_host(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
+                          const float *background, unsigned flags, uint8_t *rgb8_host, void *stream)
+{
+    return render_batch_host_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb8_host, stream, PoseSets());
+}
+
+int sas_render_batch_host_posed(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, const int *pose_set, int n_sets,
+                                const float *Rt, int width, int height, const float *background, unsigned flags,
+                                uint8_t *rgb8_host, void *stream)
+{
+    PoseSets ps;
+    ps.pose_set = pose_set; ps.n_sets = n_sets; ps.Rt = Rt;
+    if (!Rt) return fail(c, SAS_ERR_INVALID, "sas_render_batch_host_posed: Rt is required");
+    return render_batch_host_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb8_host, stream, ps);
 }
 
 int sas_wait(sas_ctx *c)
@@ -1088,7 +1222,12 @@ int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depth
         const uint32_t rr = info[4 * j + 3];
         const bool vis = rr != 0;
         const float *r = &rec[12 * j];
-        if (radii) { radii[2 * i] = vis ? (int32_t)(rr & 0xffff) : 0; radii[2 * i + 1] = vis ? (int32_t)(rr >> 16) : 0; }
+        if (radii) {   // x in info.w, y in the record's spare word: 32 bits each
+            int32_t ry;
+            memcpy(&ry, &r[11], sizeof(ry));
+            radii[2 * i] = vis ? (int32_t)rr : 0;
+            radii[2 * i + 1] = vis ? ry : 0;
+        }
         if (means2d) { means2d[2 * i] = vis ? r[0] : 0.f; means2d[2 * i + 1] = vis ? r[1] : 0.f; }
         if (depths) depths[i] = vis ? r[7] : 0.f;
         if (conics) { conics[3 * i] = vis ? r[2] : 0.f; conics[3 * i + 1] = vis ? r[3] : 0.f; conics[3 * i + 2] = vis ? r[4] : 0.f; }

@@ -7,8 +7,9 @@
 //                       SH colour, 48-byte projected record, tile rectangle; per-tile counts through
 //                       an LDS histogram over the workgroup's tile window (one global atomic per
 //                       touched tile)
-//   k_scan      T5      workgroup 0: exclusive scan of the counts (tile_offset, scatter cursors),
-//                       visible count; workgroup 1: tiles ordered by list length, sort classes
+//               T5      its LAST workgroup to finish (ticket) scans the counts: tile_offset, scatter
+//                       cursors, tiles ordered by list-length class, statistics straight to pinned host
+//                       memory -- no scan kernel, no memset, no read-back copy around a frame
 //   k_scatter   T3      (depth bits | storage slot) keys into per-tile segments, runs reserved per
 //                       (workgroup, tile) with one returning atomic
 //
@@ -182,8 +183,8 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
 // the Gaussian's 236 bytes, its group transform and its 3-D covariance are fetched / computed once,
 // and only the camera-dependent part (projection, SH direction, record, binning) runs per view --
 // the second view's input traffic, 77 % of a projection's HBM bytes, disappears.
-struct ViewSet {
-    const SasParams *P[2];
+struct ProjArgs {
+    SasCam cam[2];
     SasFrame f[2];
 };
 
@@ -286,7 +287,147 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     const unsigned long long vb = __ballot(vis);
     if ((threadIdx.x & 63) == 0 && vb) atomicAdd(s_nvis, (int)__popcll(vb));
     __syncthreads();
-    if (threadIdx.x == 0) f.wg_vis[blockIdx.x] = *s_nvis;
+    // (an agent-scope store: written through to where the tail workgroup, possibly on another XCD, reads it)
+    if (threadIdx.x == 0) __hip_atomic_store(&f.wg_vis[blockIdx.x], *s_nvis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the projection's tail (T5): offsets, cursors, tile order, statistics ---------------------------------------
+// Run by the 256 threads of the projection's last workgroup.  Thread t owns the `per` consecutive tiles from
+// t * per (a multiple of four: 16-byte loads and stores; the count array is zero-padded past its end).  Tiles are
+// ordered by list-length class (floor(log2) + 1, 15 and up together), longest first, so that long lists start early
+// in the tile kernel and short ones fill its tail: class counts in LDS bins replicated 32 times (the lanes of a wave
+// then hit different words: same-address LDS atomics serialise -- the separate scan kernel this replaces spent most
+// of its 14 us on them), one scan over the 512 (class, copy) cells, placement by returning LDS atomics.
+// Three phases, each reading the thread's counts again (32 per 16-byte-load burst: L2 hits after the first): held in
+// registers across the phases they raised the PROJECTION's register count and cost it occupancy; a lone wave issues
+// one instruction per ~7 cycles, so the phases are written for few instructions.
+DEV int len_class(int v) { return v ? min(15, 32 - __clz(v)) : 0; }
+
+DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
+{
+    const SasFrame &f = *fp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles = f.n_tiles;
+    int *s_w = lds;           // [16] cross-wave scratch
+    int *s_bins = lds + 16;   // [16 classes (descending)][32 copies]
+    const int per = (((tiles + 255) >> 8) + 3) & ~3;
+    const int t0 = tid * per;
+    const int4 *cnt4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
+    s_bins[tid] = 0;
+    s_bins[256 + tid] = 0;
+    // ---- phase 1: totals
+    int nvis = 0;
+    for (int i = tid; i < f.n_wg; i += 256) nvis += f.wg_vis[i];
+    int total = 0, maxlen = 0;
+    for (int k0 = 0; k0 < per; k0 += 32) {
+        int4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            total += (c[j].x + c[j].y) + (c[j].z + c[j].w);
+            maxlen = max(max(maxlen, max(c[j].x, c[j].y)), max(c[j].z, c[j].w));
+        }
+    }
+    int incl = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        maxlen = max(maxlen, __shfl_xor(maxlen, d));
+        nvis += __shfl_xor(nvis, d);
+    }
+    if (lane == 63) s_w[wv] = incl;
+    if (lane == 0) { s_w[4 + wv] = maxlen; s_w[8 + wv] = nvis; }
+    __syncthreads();
+    int run = incl - total;
+    for (int w = 0; w < wv; ++w) run += s_w[w];
+    const int carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    // ---- phase 2: offsets, scatter cursors, class counts
+    for (int k0 = 0; k0 < per; k0 += 32) {
+        int4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 4 * j, t = t0 + k;
+            if (k >= per || t >= tiles) continue;
+            const int4 o = make_int4(run, run + c[j].x, run + c[j].x + c[j].y, run + c[j].x + c[j].y + c[j].z);
+            run = o.w + c[j].w;
+            const int cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+            if (t + 3 < tiles) {
+                *reinterpret_cast<int4 *>(f.tile_offset + t) = o;
+                *reinterpret_cast<int4 *>(f.tile_cursor + t) = o;
+            } else {
+                const int oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t + q < tiles) { f.tile_offset[t + q] = oo[q]; f.tile_cursor[t + q] = oo[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (t + q < tiles) atomicAdd(&s_bins[(15 - len_class(cc[q])) * 32 + (lane & 31)], 1);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 512 cells, two per thread
+        const int a = s_bins[2 * tid], b = s_bins[2 * tid + 1];
+        int in2 = a + b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(in2, d);
+            if (lane >= d) in2 += o;
+        }
+        if (lane == 63) s_w[12 + wv] = in2;
+        __syncthreads();
+        int ex = in2 - (a + b);
+        for (int w = 0; w < wv; ++w) ex += s_w[12 + w];
+        s_bins[2 * tid] = ex;
+        s_bins[2 * tid + 1] = ex + a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the full path's sort classes are class ranges, hence contiguous in tile_order
+        f.sort_class[0] = 0;                        // large: length >= 4096 (classes >= 13)
+        f.sort_class[1] = s_bins[(15 - 12) * 32];   // mid:   1024..4095     (classes 11, 12)
+        f.sort_class[2] = s_bins[(15 - 10) * 32];   // small: < 1024         (classes <= 10)
+        f.sort_class[3] = tiles;
+        f.sort_class[4] = 0;                        // every tile, for the full-path blend
+        f.sort_class[5] = tiles;
+        f.tile_offset[tiles] = carry;
+        unsigned *h = f.stats_host;
+        h[0] = (unsigned)(s_w[8] + s_w[9] + s_w[10] + s_w[11]);
+        h[1] = (unsigned)carry;
+        h[2] = (long long)carry > f.cap ? 1u : 0u;
+        h[3] = 0u;
+        h[4] = (unsigned)max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
+        h[5] = f.stats[5];
+        h[6] = 0u;
+        h[7] = 0u;
+        f.stats[5] = 0u;
+    }
+    __syncthreads();   // the class starts above are read before the placement moves them
+    // ---- phase 3: placement
+    for (int k0 = 0; k0 < per; k0 += 32) {
+        int4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + k0 + 4 * j;
+            const int cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k0 + 4 * j < per && t + q < tiles) {
+                    const int pos = atomicAdd(&s_bins[(15 - len_class(cc[q])) * 32 + (lane & 31)], 1);
+                    if (SAS_IN(pos, tiles, 104)) f.tile_order[pos] = t + q;
+                }
+            if ((j & 1) == 1) asm volatile("" ::: "memory");   // eight tiles at a time: do not hold 32 atomic results
+        }
+    }
 }
 
 // Scene loads.  A view pair streams the scene once, non-temporally, so that it does not evict the records
@@ -301,7 +442,7 @@ DEV float4 scene_load(const float4 *p)
 }
 
 template <int DEG, int NV>
-DEV void project_body(const SasScene &s, const ViewSet &vs)
+DEV void project_body(const SasScene &s, const ProjArgs &vs)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < s.n;
@@ -317,8 +458,8 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
         float m[3] = {a0.x, a0.y, a0.z};
         const float op = a0.w;
         const float *G = nullptr;
-        if (s.group_Rt) {
-            G = s.group_Rt + 12 * (__float_as_uint(a2.w) & 255u);
+        if (vs.f[0].group_Rt) {   // the views of one pass share their group poses
+            G = vs.f[0].group_Rt + 12 * (__float_as_uint(a2.w) & 255u);
             float mg0 = affine3(G[0], G[1], G[2], G[3], m[0], m[1], m[2]);
             float mg1 = affine3(G[4], G[5], G[6], G[7], m[0], m[1], m[2]);
             float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
@@ -328,7 +469,7 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
         bool ok[NV], any_ok = false;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const SasCam &c = vs.P[v]->cam;   // wave-uniform: scalar loads
+            const SasCam &c = vs.cam[v];   // argument segment: scalar loads
             cx[v] = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);
             cy[v] = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
             cz[v] = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
@@ -386,7 +527,7 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
             bool any_vis = false;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                if (ok[v]) project_view(vs.P[v]->cam, cov, op, cx[v], cy[v], cz[v], g[v]);
+                if (ok[v]) project_view(vs.cam[v], cov, op, cx[v], cy[v], cz[v], g[v]);
                 any_vis = any_vis || g[v].vis;
             }
             if (any_vis) {
@@ -402,7 +543,7 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     if (!g[v].vis) continue;
-                    const SasCam &c = vs.P[v]->cam;
+                    const SasCam &c = vs.cam[v];
                     float rgb[3];
                     if constexpr (DEG >= 0) {
                         sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
@@ -412,9 +553,12 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
                     const SasFrame &f = vs.f[v];
                     f.rec[3 * i + 0] = make_float4(g[v].mx, g[v].my, g[v].ca, g[v].cb);
                     f.rec[3 * i + 1] = make_float4(g[v].ccn, op, g[v].thr, g[v].z);
-                    f.rec[3 * i + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                    // radii (parity hook only): x in info.w, y in the record's spare word -- full 32 bits each (a camera
+                    // inside the cloud produces radii beyond 65535 pixels); saturated to INT_MAX
+                    const int irx = (int)fminf(g[v].rx, 2147483520.0f), iry = (int)fminf(g[v].ry, 2147483520.0f);
+                    f.rec[3 * i + 2] = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(iry));
                     f.info[i] = make_uint4((unsigned)g[v].x0 | ((unsigned)g[v].x1 << 16), (unsigned)g[v].y0 | ((unsigned)g[v].y1 << 16),
-                                           __float_as_uint(g[v].z), (unsigned)(int)g[v].rx | ((unsigned)(int)g[v].ry << 16));
+                                           __float_as_uint(g[v].z), (unsigned)irx);
                 }
             }
         }
@@ -426,11 +570,44 @@ DEV void project_body(const SasScene &s, const ViewSet &vs)
     __shared__ int s_hist[kHistBins];
     __shared__ int s_nvis;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.P[v]->cam.tw, g[v], s_win, s_hist, &s_nvis);
+    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], s_win, s_hist, &s_nvis);
+    // ---- the last workgroup to get here scans the counts of the frame(s).
+    // Everything the tail reads from other workgroups was written by AGENT-scope atomics (the per-tile counts, the
+    // window-miss counter, wg_vis below), which are performed at the point all XCDs share; what remains is ordering:
+    // every wave waits until its own outstanding stores and atomics have been acknowledged (s_waitcnt vmcnt(0) -- the
+    // wait an agent-scope release consists of, without its cache write-back; a workgroup-scope fence compiles to
+    // nothing here), the barrier collects the waves, then thread 0 takes the ticket.  A __threadfence() in this place
+    // -- a write-back of the XCD's whole L2 by every workgroup while the projection streams 60 MB of records through
+    // it -- cost 740 us per launch.
+    // The ticket has two levels: same-address atomics serialise at ~90 per us at the memory side, and 3 907
+    // workgroups taking one counter cost the projection 23 us; 64 sub-counters (one cache line each) take ~61
+    // tickets each, the last taker of each takes one of 64 master tickets.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *tk = vs.f[0].tickets;
+        const unsigned sub = blockIdx.x & 63u, n_sub = (gridDim.x - sub + 63u) >> 6, subs = min(gridDim.x, 64u);
+        int last = 0;
+        if (atomicAdd(&tk[32u * sub], 1u) == n_sub - 1u) {
+            tk[32u * sub] = 0u;                                   // nobody else touches it any more in this frame
+            last = atomicAdd(&tk[32u * 64u], 1u) == subs - 1u;
+            if (last) tk[32u * 64u] = 0u;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the tail's loads below are not served from a stale cache line
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        scan_tail(&vs.f[v], s_hist);
+        __syncthreads();
+    }
 }
 
 template <int DEG, int NV>
-__global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
+__global__ __launch_bounds__(256) void k_project(SasScene s, ProjArgs vs)
 {
     project_body<DEG, NV>(s, vs);
 }
@@ -439,179 +616,37 @@ __global__ __launch_bounds__(256) void k_project(SasScene s, ViewSet vs)
 template <int DEG>
 __global__ __launch_bounds__(256) void k_project_multi(SasScene s, SasMulti mf)
 {
-    ViewSet vs;
-    vs.P[0] = vs.P[1] = mf.P[blockIdx.y];
+    ProjArgs vs;
+    vs.cam[0] = vs.cam[1] = mf.P[blockIdx.y].cam;
     vs.f[0] = vs.f[1] = mf.f[blockIdx.y];
     project_body<DEG, 1>(s, vs);
 }
 
-// ---- k_scan: exclusive scan over tiles (workgroup 0) + tile order (workgroup 1) -------------------
-// Each thread owns 8 consecutive tiles per round and loads them before anything else, so a round
-// costs one memory latency (the counts were written by memory-side atomics and miss every cache).
-// Also: blend launch order (tiles bucketed by floor(log2(length)), longest first, so long lists
-// start early and short ones fill the tail), visible count, max list length, overflow flag.
-constexpr int kScanPer = 8;
-
-DEV void scan_body(const SasFrame &f, int tiles)
-{
-    __shared__ int wsum[16];
-    __shared__ int s_bucket[33];
-    __shared__ int s_bbase[33];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int rounds = (tiles + 1024 * kScanPer - 1) / (1024 * kScanPer);
-
-    if (blockIdx.x == 1) {
-        // ---- workgroup 1: blend launch order and sort classes (independent of the offsets)
-        if (tid < 33) s_bucket[tid] = 0;
-        __syncthreads();
-        int v0[kScanPer];
-        for (int r = 0; r < rounds; ++r) {
-            const int base = (r * 1024 + tid) * kScanPer;
-            int v[kScanPer];
-#pragma unroll
-            for (int k = 0; k < kScanPer; ++k) v[k] = (base + k < tiles) ? f.tile_count[base + k] : 0;
-            if (r == 0) {
-#pragma unroll
-                for (int k = 0; k < kScanPer; ++k) v0[k] = v[k];
-            }
-#pragma unroll
-            for (int k = 0; k < kScanPer; ++k)
-                if (base + k < tiles) atomicAdd(&s_bucket[v[k] ? 32 - __clz(v[k]) : 0], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int bkt = 32; bkt >= 0; --bkt) { s_bbase[bkt] = run; run += s_bucket[bkt]; }
-            // bucket b holds lengths [2^(b-1), 2^b): sort classes are bucket ranges, hence contiguous
-            f.sort_class[0] = 0;             // large: length >= 4096 (buckets >= 13)
-            f.sort_class[1] = s_bbase[12];   // mid:   1024..4095     (buckets 11, 12)
-            f.sort_class[2] = s_bbase[10];   // small: < 1024         (buckets <= 10)
-            f.sort_class[3] = tiles;
-            f.sort_class[4] = 0;             // every tile, for the full-path blend
-            f.sort_class[5] = tiles;
-        }
-        __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            const int base = (r * 1024 + tid) * kScanPer;
-#pragma unroll
-            for (int k = 0; k < kScanPer; ++k)
-                if (base + k < tiles) {
-                    const int v = (r == 0) ? v0[k] : f.tile_count[base + k];
-                    f.tile_order[atomicAdd(&s_bbase[v ? 32 - __clz(v) : 0], 1)] = base + k;
-                }
-        }
-        return;
-    }
-
-    // ---- workgroup 0: offsets, scatter cursors, visible count, max list length, overflow flag
-    int nvis = 0;
-    for (int i0 = 0; i0 < f.n_wg; i0 += 1024 * 8) {
-        int part[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 1024 + tid;
-            part[u] = (i < f.n_wg) ? f.wg_vis[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) nvis += part[u];
-    }
-    int carry = 0, maxlen = 0;
-    for (int r = 0; r < rounds; ++r) {
-        const int base = (r * 1024 + tid) * kScanPer;
-        int v[kScanPer];
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k) v[k] = (base + k < tiles) ? f.tile_count[base + k] : 0;
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k) {
-            sum += v[k];
-            maxlen = max(maxlen, v[k]);
-        }
-        int incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        int woff = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int x = wsum[k];
-            if (k < wv) woff += x;
-            total += x;
-        }
-        int run = carry + woff + incl - sum;
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k) {
-            if (base + k < tiles) { f.tile_offset[base + k] = run; f.tile_cursor[base + k] = run; }
-            run += v[k];
-        }
-        carry += total;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        maxlen = max(maxlen, __shfl_xor(maxlen, d));
-        nvis += __shfl_xor(nvis, d);
-    }
-    if (lane == 0) {
-        atomicMax(&f.stats[4], (unsigned)maxlen);
-        if (nvis) atomicAdd(&f.stats[0], (unsigned)nvis);
-    }
-    if (tid == 0) {
-        f.tile_offset[tiles] = carry;
-        f.stats[1] = (unsigned)carry;
-        if ((long long)carry > f.cap) f.stats[2] = 1u;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_scan(SasFrame f, int tiles) { scan_body(f, tiles); }
-__global__ __launch_bounds__(1024) void k_scan_multi(SasMulti mf, int tiles) { scan_body(mf.f[blockIdx.y], tiles); }
-
-// ---- frame prologue / epilogue (SasFrameIo) ----------------------------------------------------------
-// grid = (blocks covering the largest counter block, views).  The parameter block and the group poses come
-// straight from pinned host memory: a few hundred bytes, read once, by the first block of each view.
-// The parameter blocks (and up to kInlineGroups group poses) travel in the kernel's ARGUMENT segment, which the
-// command processor hands to the kernel without a PCIe round trip; more groups than that are read from pinned host
-// memory by the kernel itself.
-constexpr int kInlineGroups = 16;
-struct SasPrologueArgs {
-    SasFrameIo io;
-    SasParams params[SAS_MAX_GROUP];
-    float groups[12 * kInlineGroups];
-    int groups_inline;
+// ---- small kernels around a frame ---------------------------------------------------------------------
+// Group poses of the views of a launch (SasPoseUpload): from the ARGUMENT segment, which the command processor
+// hands to the kernel without a PCIe round trip, or -- more rows than fit there -- read from pinned host memory by
+// the kernel itself.  grid.x = view.
+struct SasPoseArgs {
+    SasPoseUpload u;
+    int inline_off[SAS_MAX_GROUP];
+    int use_inline;
+    float rows[12 * SAS_POSE_INLINE_ROWS];
 };
-__global__ __launch_bounds__(256) void k_frame_prologue(SasPrologueArgs a)
+__global__ __launch_bounds__(256) void k_pose_upload(SasPoseArgs a)
 {
-    const SasFrameIo &io = a.io;
-    const int v = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < io.counter_words[v]) io.counters[v][i] = 0u;
-    if (blockIdx.x == 0) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(&a.params[v]);
-        unsigned *dst = reinterpret_cast<unsigned *>(io.params_dev[v]);
-        for (int k = threadIdx.x; k < (int)(sizeof(SasParams) / sizeof(unsigned)); k += 256) dst[k] = src[k];
-        if (v == 0 && io.groups_dev) {
-            const float *g = a.groups_inline ? a.groups : io.groups_host;
-            for (int k = threadIdx.x; k < io.group_floats; k += 256) io.groups_dev[k] = g[k];
-        }
-    }
+    const int v = blockIdx.x;
+    const float *src = a.use_inline ? a.rows + a.inline_off[v] : a.u.src_host[v];
+    float *dst = a.u.dst[v];
+    for (int k = threadIdx.x; k < a.u.floats[v]; k += 256) dst[k] = src[k];
 }
-// grid = (blocks, views): block (0, 0) writes the statistics words of all views; every block copies its share of
-// its view's uint8 frame to pinned host memory, 16 bytes per lane where source, destination and size allow.
-__global__ __launch_bounds__(256) void k_frame_epilogue(SasFrameIo io)
+// grid = (blocks, views): every block copies its share of its view's uint8 frame to pinned host memory, 16 bytes per
+// lane where source, destination and size allow.
+__global__ __launch_bounds__(256) void k_host_copy(SasHostCopy h)
 {
-    if (io.want_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
-        const int v = threadIdx.x >> 3, w = threadIdx.x & 7;
-        if (v < io.nv) io.stats_host[v][w] = io.counters[v][w];
-    }
-    if (io.host_bytes == 0) return;
-    const uint8_t *src = io.host_src[blockIdx.y];
-    uint8_t *dst = io.host_dst[blockIdx.y];
+    const uint8_t *src = h.src[blockIdx.y];
+    uint8_t *dst = h.dst[blockIdx.y];
     if (!src || !dst) return;
-    const size_t n = io.host_bytes, stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = h.bytes, stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
         uint4 *d4 = reinterpret_cast<uint4 *>(dst);
@@ -696,9 +731,9 @@ void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *pe
 }
 
 template <int NV>
-static void launch_project(hipStream_t st, const SasScene &s, const ViewSet &vs)
+static void launch_project(hipStream_t st, const SasScene &s, const ProjArgs &vs)
 {
-    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    const unsigned grid = (unsigned)vs.f[0].n_wg;   // >= 1: an empty scene still takes the tail
     switch (s.sh_degree) {
         case 0: hipLaunchKernelGGL((k_project<0, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
         case 1: hipLaunchKernelGGL((k_project<1, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
@@ -708,29 +743,26 @@ static void launch_project(hipStream_t st, const SasScene &s, const ViewSet &vs)
     }
 }
 
-void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams *P, const SasFrame &f)
+void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams &P, const SasFrame &f)
 {
-    if (s.n <= 0) return;
-    ViewSet vs;
-    vs.P[0] = P; vs.P[1] = P;
-    vs.f[0] = f; vs.f[1] = f;
+    ProjArgs vs;
+    vs.cam[0] = vs.cam[1] = P.cam;
+    vs.f[0] = vs.f[1] = f;
     launch_project<1>(st, s, vs);
 }
 
-void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams *P0, const SasFrame &f0, const SasParams *P1,
+void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams &P0, const SasFrame &f0, const SasParams &P1,
                          const SasFrame &f1)
 {
-    if (s.n <= 0) return;
-    ViewSet vs;
-    vs.P[0] = P0; vs.P[1] = P1;
+    ProjArgs vs;
+    vs.cam[0] = P0.cam; vs.cam[1] = P1.cam;
     vs.f[0] = f0; vs.f[1] = f1;
     launch_project<2>(st, s, vs);
 }
 
 void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti &mf)
 {
-    if (s.n <= 0) return;
-    const dim3 grid((unsigned)((s.n + 255) / 256), (unsigned)mf.nv);
+    const dim3 grid((unsigned)mf.f[0].n_wg, (unsigned)mf.nv);
     switch (s.sh_degree) {
         case 0: hipLaunchKernelGGL((k_project_multi<0>), grid, dim3(256), 0, st, s, mf); break;
         case 1: hipLaunchKernelGGL((k_project_multi<1>), grid, dim3(256), 0, st, s, mf); break;
@@ -740,46 +772,37 @@ void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti 
     }
 }
 
-void sas_launch_scan_multi(hipStream_t st, int tiles, const SasMulti &mf)
-{
-    hipLaunchKernelGGL(k_scan_multi, dim3(2, (unsigned)mf.nv), dim3(1024), 0, st, mf, tiles);
-}
-
 void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf)
 {
     if (s.n <= 0) return;
     hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 255) / 256), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
 }
 
-void sas_launch_frame_prologue(hipStream_t st, const SasFrameIo &io)
+void sas_launch_pose_upload(hipStream_t st, const SasPoseUpload &u)
 {
-    static_assert(sizeof(SasParams) % sizeof(unsigned) == 0, "parameter block is copied word by word");
-    static_assert(sizeof(SasPrologueArgs) <= 4096, "kernel argument segment");
-    SasPrologueArgs a{};
-    a.io = io;
-    int words = 1;
-    for (int v = 0; v < io.nv; ++v) {
-        words = io.counter_words[v] > words ? io.counter_words[v] : words;
-        a.params[v] = *io.params_host[v];
+    static_assert(sizeof(SasPoseArgs) <= 4096, "kernel argument segment");
+    SasPoseArgs a{};
+    a.u = u;
+    int total = 0;
+    for (int v = 0; v < u.nv; ++v) total += u.floats[v];
+    a.use_inline = total <= 12 * SAS_POSE_INLINE_ROWS;
+    if (a.use_inline) {
+        int off = 0;
+        for (int v = 0; v < u.nv; ++v) {
+            a.inline_off[v] = off;
+            for (int k = 0; k < u.floats[v]; ++k) a.rows[off + k] = u.src_host[v][k];
+            off += u.floats[v];
+        }
     }
-    a.groups_inline = io.groups_dev && io.group_floats <= 12 * kInlineGroups;
-    if (a.groups_inline)
-        for (int k = 0; k < io.group_floats; ++k) a.groups[k] = io.groups_host[k];
-    hipLaunchKernelGGL(k_frame_prologue, dim3((unsigned)((words + 255) / 256), (unsigned)io.nv), dim3(256), 0, st, a);
-}
-void sas_launch_frame_epilogue(hipStream_t st, const SasFrameIo &io)
-{
-    unsigned blocks = 1;
-    if (io.host_bytes) {
-        const size_t units = (io.host_bytes + 16 * 256 - 1) / (16 * 256);
-        blocks = (unsigned)(units < 128 ? (units ? units : 1) : 128);
-    }
-    hipLaunchKernelGGL(k_frame_epilogue, dim3(blocks, io.host_bytes ? (unsigned)io.nv : 1u), dim3(256), 0, st, io);
+    hipLaunchKernelGGL(k_pose_upload, dim3((unsigned)u.nv), dim3(256), 0, st, a);
 }
 
-void sas_launch_scan(hipStream_t st, int tiles, const SasFrame &f)
+void sas_launch_host_copy(hipStream_t st, const SasHostCopy &h)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, st, f, tiles);
+    if (h.bytes == 0 || h.nv <= 0) return;
+    const size_t units = (h.bytes + 16 * 256 - 1) / (16 * 256);
+    const unsigned blocks = (unsigned)(units < 128 ? (units ? units : 1) : 128);
+    hipLaunchKernelGGL(k_host_copy, dim3(blocks, (unsigned)h.nv), dim3(256), 0, st, h);
 }
 
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f)

@@ -212,6 +212,47 @@ DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *
     for (int i = tid; i < n; i += nthreads) out[i] = (int)lo32(g[i]);
 }
 
+// The same network on storage SLOTS: `ids` receives the low words of the (untouched) keys and is ordered in place by
+// (depth word of the slot, caller index); the depth words are gathered from the projection's info.  For the quad
+// layout, where the key segment must stay read-only (see tile_lazy_body).  A real call: rare path, keeps the
+// common one's registers.
+__device__ __attribute__((noinline)) void sort_ids_bitonic(const unsigned long long *g, int *ids, int n, const uint4 *info, const int *perm)
+{
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int i = tid; i < n; i += nthreads) ids[i] = (int)lo32(g[i]);
+    __threadfence_block();
+    __syncthreads();
+    auto greater = [&](int a, int b) {
+        const unsigned da = info[a].z, db = info[b].z;
+        return da != db ? da > db : perm[a] > perm[b];
+    };
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = tid; p < (P >> 1); p += nthreads) {
+            const int blk = (p / hk) * k, o = p % hk;
+            const int l = blk + o, r = blk + k - 1 - o;
+            if (r < n) {
+                const int a = ids[l], b = ids[r];
+                if (greater(a, b)) { ids[l] = b; ids[r] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int p = tid; p < (P >> 1); p += nthreads) {
+                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int r = l | j;
+                if (r < n) {
+                    const int a = ids[l], b = ids[r];
+                    if (greater(a, b)) { ids[l] = b; ids[r] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ================================================================================================
 // Full path, stage 1: k_sort_* write every tile's complete front-to-back list (storage slots)
 // ================================================================================================
@@ -933,8 +974,13 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                     p.T = Tn;
                     // acc = fma(colour of entry j (lane j of the quad), weight, acc): the broadcast rides on the
                     // multiply-add as a DPP operand (hipcc leaves a v_mov_dpp + s_nop in front of each otherwise)
-#define SAS_QFMAC(ACC_, COL_, WGT_, J) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ACC_) : "v"(COL_), "v"(WGT_))
+#define SAS_QFMAC(ACC_, COL_, WGT_, J) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ACC_) : "v"(COL_), "v"(WGT_))
 #define SAS_QACC(WGT_, J) SAS_QFMAC(p.r, C.x, WGT_, J); SAS_QFMAC(p.g, C.y, WGT_, J); SAS_QFMAC(p.b, C.z, WGT_, J); SAS_QFMAC(p.d, C.w, WGT_, J)
+                    // Two wait states must lie between a VALU write of a VGPR and a DPP read of it (gfx9), and the
+                    // hazard recogniser does not look inside inline asm.  C comes straight from ds_read_b128 today; the
+                    // s_nop covers a copy of it a future register allocation might put in front of this block (the
+                    // statements are volatile: they stay behind it, in this order).
+                    asm volatile("s_nop 1");
                     SAS_QACC(v0, 0);
                     SAS_QACC(v1, 1);
                     SAS_QACC(v2, 2);
@@ -996,13 +1042,13 @@ DEV void store_tile_max(const SasFrame &f, int tile, float ED, unsigned *s_wmax)
 
 // ---- full path, stage 2: composite the complete sorted lists -----------------------------------
 template <bool FAST_EXP, bool WANT_MAX>
-__global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, SasFrame f, long long n_gauss,
+__global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long long n_gauss,
                                                const int *tl, const int *range)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlendLdsBytes];
     __shared__ unsigned s_wmax[4];
-    const SasCam &c = P->cam;
-    const SasOutputs o = P->out;
+    const SasCam &c = P.cam;
+    const SasOutputs &o = P.out;
     const BlendLds L = blend_lds(s_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
@@ -1022,6 +1068,7 @@ __global__ __launch_bounds__(256) void k_blend(const SasParams *__restrict__ P, 
                               [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
         const float ED = write_pixel(o, p, inside, ix, iy, c.W);
         if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+        if (tid == 0) f.tile_count[tile] = 0;   // the frame's counters leave the frame zeroed (SasFrame invariant)
     }
 }
 
@@ -1076,7 +1123,7 @@ __device__ __attribute__((noinline)) void partition_by_bucket(const unsigned lon
 }
 
 template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
-DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long long n_gauss, const int *perm, unsigned wg /* workgroup index within the view */)
+DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss, const int *perm, unsigned wg /* workgroup index within the view */)
 {
     // timing experiments only (-DSAS_TUNE_ABLATE=1: no chunk sort, =2: no compositing): wrong images
 #ifdef SAS_TUNE_ABLATE
@@ -1094,8 +1141,8 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     __shared__ unsigned s_wsum[4], s_wmax[4];
     __shared__ unsigned s_mn, s_mx, s_m;
     __shared__ int s_b1;
-    const SasCam &c = P->cam;
-    const SasOutputs o = P->out;
+    const SasCam &c = P.cam;
+    const SasOutputs &o = P.out;
     const BlendLds L = blend_lds(s_raw);
     unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);          // [4][256]   (sort phase)
     unsigned *dbase = cnt + 4 * 256;                              // [256]
@@ -1238,9 +1285,11 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
         }
         __syncthreads();
         int b_next = 0;
-        // QUAD: the complete ordering below works in place on the tile's segments, which the four workgroups of
-        // a tile share; so the decision is taken here, from the histogram all four see alike, and quadrant 0
-        // alone renders such a tile (in the ordinary layout) while the others leave
+        // QUAD: a tile's four workgroups share its global segments and are not synchronised with each other, so
+        // every one of them treats the KEY segment as read-only for the whole kernel: the decision for the complete
+        // ordering is taken here, from the histogram of keys nobody changes (all four arrive at the same answer);
+        // quadrant 0 alone then renders such a tile (in the ordinary layout), ordering storage slots in the id
+        // segment -- which only it touches -- by the depth words of the projection's info; the others leave.
         bool bail = QUAD ? (bool)__syncthreads_or(s_hist[tid] > (unsigned)CH) : false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
         int p_consumed = 0;                       // ... and this many of them have been composited since
@@ -1365,9 +1414,10 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
             if (QUAD && qd != 0) {
                 writer = false;
             } else {
-                if (tid == 0) atomicAdd(&f.stats[6], 1u);
+                if (tid == 0) __hip_atomic_fetch_add(&f.stats_host[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 int *out = f.sorted_ids + beg;
-                sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
+                if (QUAD) sort_ids_bitonic(f.keys + beg, out, n, f.info, perm);
+                else sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
                 __syncthreads();
                 if (QUAD) {   // the whole tile, ordinary layout
                     pixel_of(wv, lane, ox, oy);
@@ -1385,6 +1435,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
     }
     const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W);
     if (WANT_MAX) store_tile_max(f, QUAD ? 4 * tile + qd : tile, ED, s_wmax);   // QUAD: one slot per quadrant (k_depth_tail reduces 4 x tiles)
+    if (tid == 0 && qd == 0) f.tile_count[tile] = 0;   // the frame's counters leave the frame zeroed (SasFrame invariant)
 #ifdef SAS_TUNE_WGTIME
     if (tid == 0 && blockIdx.x < kDbgWgMax) {
         g_dbg_wg[3 * blockIdx.x] = t_wg0;
@@ -1396,7 +1447,7 @@ DEV void tile_lazy_body(const SasParams *__restrict__ P, const SasFrame &f, long
 
 #define SAS_LAZY_ATTRS __attribute__((amdgpu_flat_work_group_size(kLazyThreads, kLazyThreads), amdgpu_waves_per_eu(SAS_TUNE_OCC, SAS_TUNE_OCC)))
 template <bool FAST_EXP, bool WANT_MAX, bool QUAD>
-__global__ SAS_LAZY_ATTRS void k_tile_lazy(const SasParams *__restrict__ P, SasFrame f, long long n_gauss, const int *perm)
+__global__ SAS_LAZY_ATTRS void k_tile_lazy(SasParams P, SasFrame f, long long n_gauss, const int *perm)
 {
     tile_lazy_body<FAST_EXP, WANT_MAX, QUAD>(P, f, n_gauss, perm, blockIdx.x);
 }
@@ -1417,13 +1468,13 @@ __global__ SAS_LAZY_ATTRS void k_tile_lazy_multi(SasMulti mf, long long n_gauss,
 // PTS: the RGB-D consumer of nerfstudio_utils.py:424-445 fused into the same pass:
 //   x = (u - cx) * d / fx, y = (v - cy) * d / fy, z = d;  mask = d < max_depth.
 template <bool FILL, bool PTS>
-__global__ __launch_bounds__(256) void k_depth_tail(const unsigned *tile_max, int tiles, const SasParams *__restrict__ P)
+__global__ __launch_bounds__(256) void k_depth_tail(const unsigned *tile_max, int tiles, SasParams P)
 {
     __shared__ unsigned s_max[4];
-    const SasOutputs o = P->out;
+    const SasOutputs &o = P.out;
     float *depth = o.depth;
-    const int W = P->cam.W;
-    const long long npix = (long long)W * P->cam.H;
+    const int W = P.cam.W;
+    const long long npix = (long long)W * P.cam.H;
     float mx = 0.0f;
     if (FILL) {
         unsigned m = 0;
@@ -1434,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_depth_tail(const unsigned *tile_max, in
         __syncthreads();
         mx = __uint_as_float(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
     }
-    const float fx = P->cam.fx, fy = P->cam.fy, cx = P->cam.cx, cy = P->cam.cy;
+    const float fx = P.cam.fx, fy = P.cam.fy, cx = P.cam.cx, cy = P.cam.cy;
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
         float d = depth[p];
         if (FILL && d == 0.0f) {
@@ -1509,13 +1560,13 @@ void sas_launch_sort(hipStream_t st, const SasScene &s, int ntiles, const SasFra
 }
 
 template <bool FAST, bool WMAX>
-static void launch_blend_list(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n,
+static void launch_blend_list(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n,
                               const int *tl, const int *range)
 {
     hipLaunchKernelGGL((k_blend<FAST, WMAX>), dim3(grid), dim3(256), 0, st, P, f, n, tl, range);
 }
 
-static void blend_list(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *tl,
+static void blend_list(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n, const int *tl,
                        const int *range, bool fast_exp, bool want_max)
 {
     if (fast_exp) {
@@ -1528,7 +1579,7 @@ static void blend_list(hipStream_t st, unsigned grid, const SasParams *P, const 
 }
 
 // Full path, stage 2: composite all tiles from their complete lists (longest first).
-void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams &P, const SasFrame &f,
                       bool fast_exp, bool want_max)
 {
     const long long n = s.n > 0 ? s.n : 1;
@@ -1540,7 +1591,7 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 // (SAS_FAST_EXP frames take the ordinary layout).  The caller sizes tile_max for 4 x tiles and passes 4 x tiles
 // to sas_launch_depth_tail when it chose quad.
 template <bool FAST, bool WMAX, bool QUAD>
-static void launch_lazy(hipStream_t st, unsigned grid, const SasParams *P, const SasFrame &f, long long n, const int *perm,
+static void launch_lazy(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n, const int *perm,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
@@ -1551,7 +1602,7 @@ static void launch_lazy(hipStream_t st, unsigned grid, const SasParams *P, const
 
 bool sas_tiles_lazy_quad_ok(bool fast_exp) { return !fast_exp; }
 
-void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams *P, const SasFrame &f,
+void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams &P, const SasFrame &f,
                            bool fast_exp, bool want_max, bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const unsigned grid = (unsigned)tiles;
@@ -1594,7 +1645,7 @@ void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, c
     }
 }
 
-void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams *P, const SasFrame &f, bool fill, bool points)
+void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams &P, const SasFrame &f, bool fill, bool points)
 {
     const unsigned *tm = (const unsigned *)f.tile_max;
     if (fill && points) hipLaunchKernelGGL((k_depth_tail<true, true>), dim3(1024), dim3(256), 0, st, tm, tiles, P);

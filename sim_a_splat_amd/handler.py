@@ -115,6 +115,12 @@ class SplatHandler:
         rest = ~self.robot_splat_idxs                          # "/scene_ohne_robot" (:112-119)
         self.scene_handle = self.scene.add_gaussian_splats("/scene_ohne_robot", means[rest], covs[rest], colors[rest],
                                                            opacities[rest])
+        # the draw message's pose algebra runs inside the library when the scene offers it (sas_set_link_poses)
+        self._k_fast = min(len(self.fk), 7, len(self.splat_links_handler))
+        self._fast = hasattr(self.scene, "set_link_poses") and self._k_fast > 0
+        if self._fast:
+            self.scene.set_link_constants(self.scale_factor, self.Ri, self.ti, self._fkR[:self._k_fast], self._fkt[:self._k_fast],
+                                          self.weld_translation, [h.index for h in self.splat_links_handler[:self._k_fast]])
 
     @classmethod
     def from_assets(cls, loader, masks_dir, urdf_path, bounds=None, **kw) -> "SplatHandler":
@@ -146,12 +152,22 @@ class SplatHandler:
             return
         q = np.asarray([msg.quaternion[i] for i in idxs[:k]], dtype=np.float64)
         p = np.asarray([msg.position[i] for i in idxs[:k]], dtype=np.float64)
+        if self._fast:
+            self.scene.set_link_poses(q, p)      # float64 in C, the arithmetic below; handles read their rows back on demand
+            return
         R, t = poses.link_splat_poses(self.scale_factor, self.Ri, self.ti, self._fkR[:k], self._fkt[:k], q, p, self.weld_translation)
         wxyz = poses.matrices_to_quats_wxyz(R)
-        for j in range(k):
-            h = self.splat_links_handler[j]
-            h.wxyz = wxyz[j]
-            h.position = t[j]
+        lock = getattr(self.scene, "lock", None)
+        if lock is not None:
+            lock.acquire()      # the k assignments are ONE update: a render on another thread sees all or none of it
+        try:
+            for j in range(k):
+                h = self.splat_links_handler[j]
+                h.wxyz = wxyz[j]
+                h.position = t[j]
+        finally:
+            if lock is not None:
+                lock.release()
 
     def get_attached_frame(self, body_name: str, local_frame_pos, msg) -> Tuple[np.ndarray, np.ndarray]:
         """``local_frame_pos``: the camera's ``local_frame`` (SE3-like, as the reference passes it, :316-319) or

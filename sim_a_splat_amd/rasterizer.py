@@ -6,6 +6,8 @@ arithmetic of the frame happens in libsas_hip.so.
 from __future__ import annotations
 
 import ctypes
+import functools
+import threading
 from typing import Dict, Iterable, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -38,8 +40,20 @@ def cov3x3_to_cov6(cov: ArrayLike) -> ArrayLike:
     return np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
 
 
+def _locked(fn):
+    """One caller at a time per context: the C ABI is not re-entrant (include/sim_a_splat_amd.h), and the reference's
+    callers are not always single-threaded -- demo_hw_splat.py drives env.step from a ROS2 callback thread
+    (examples/demo_hw_splat.py:113-136) while a viewer thread may render through the same scene."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 class Rasterizer:
-    """MI355X Gaussian-splat rasterizer context (HIP, gfx950)."""
+    """MI355X Gaussian-splat rasterizer context (HIP, gfx950).  Every method that enters the C ABI holds the
+    context's lock (re-entrant: a thread may nest calls)."""
 
     def __init__(self, device: Union[int, str, torch.device] = 0):
         if not torch.cuda.is_available():
@@ -48,6 +62,7 @@ class Rasterizer:
         if dev.type != "cuda":
             raise SasError(f"Rasterizer needs a cuda (HIP) device, got {dev}")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self._lock = threading.RLock()
         self._L = _capi.lib()
         self._ctx = ctypes.c_void_p()
         rc = self._L.sas_create(self.device.index, ctypes.byref(self._ctx))
@@ -58,6 +73,7 @@ class Rasterizer:
         self._keep = []  # outputs of in-flight async frames (the C ABI keeps up to four)
 
     # -- lifetime ---------------------------------------------------------------------------
+    @_locked
     def close(self) -> None:
         if getattr(self, "_ctx", None) and self._ctx.value:
             self._L.sas_destroy(self._ctx)
@@ -73,6 +89,7 @@ class Rasterizer:
         _capi.check(self._ctx, rc, what)
 
     # -- scene ------------------------------------------------------------------------------
+    @_locked
     def upload(self, means: ArrayLike, opacities: ArrayLike, colors: ArrayLike, *, quats: Optional[ArrayLike] = None,
                scales: Optional[ArrayLike] = None, covariances: Optional[ArrayLike] = None, sh_degree: int = 3,
                group_id: Optional[ArrayLike] = None, n_groups: int = 0) -> None:
@@ -111,11 +128,46 @@ class Rasterizer:
         self.n = n
         self.n_groups = int(n_groups) if group_id is not None else 0
 
+    @_locked
     def set_group_poses(self, Rt: ArrayLike) -> None:
-        """[G,12] (or [G,3,4]) row-major (R|t) per splat group."""
+        """[G,12] (or [G,3,4]) row-major (R|t) per splat group: the poses of the frames submitted from now on
+        (frames in flight keep the poses they were submitted with; nothing is waited for)."""
         arr = np.ascontiguousarray(np.asarray(Rt.cpu() if isinstance(Rt, torch.Tensor) else Rt, dtype=np.float32)).reshape(-1, 12)
         self._check(self._L.sas_set_group_poses(self._ctx, arr.shape[0], arr.ctypes.data_as(ctypes.c_void_p)),
                     "sas_set_group_poses")
+
+    @_locked
+    def set_link_constants(self, scale: float, Ri, ti, Rfk, tfk, weld=None, groups=None) -> None:
+        """Constants of the per-link pose algebra (sas_set_link_constants): ICP similarity ``(scale, Ri [3,3], ti [3])``,
+        per-link mask-time forward kinematics ``Rfk [K,3,3]``, ``tfk [K,3]``, weld translation, the group each link drives."""
+        f64 = lambda a, shape: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
+        Rfk = f64(Rfk, (-1, 9))
+        K = Rfk.shape[0]
+        Ri, ti, tfk = f64(Ri, (9,)), f64(ti, (3,)), f64(tfk, (K, 3))
+        w = f64(weld, (3,)) if weld is not None else None
+        g = np.ascontiguousarray(np.asarray(groups, dtype=np.int32).reshape(K)) if groups is not None else None
+        self._check(self._L.sas_set_link_constants(self._ctx, K, float(scale), Ri.ctypes.data, ti.ctypes.data, Rfk.ctypes.data,
+                                                   tfk.ctypes.data, w.ctypes.data if w is not None else None,
+                                                   g.ctypes.data if g is not None else None), "sas_set_link_constants")
+
+    @_locked
+    def set_link_poses(self, q_msg, p_msg, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """A draw message's link poses (``q_msg [k,4]`` wxyz, ``p_msg [k,3]``) -> group poses, evaluated inside the
+        library (sas_set_link_poses); ``out`` (float32, ``n_groups * 12`` elements) receives all current group poses."""
+        q = np.ascontiguousarray(np.asarray(q_msg, dtype=np.float64).reshape(-1, 4))
+        p = np.ascontiguousarray(np.asarray(p_msg, dtype=np.float64).reshape(-1, 3))
+        if out is not None and not (out.dtype == np.float32 and out.flags.c_contiguous and out.size == 12 * self.n_groups):
+            raise ValueError("out must be a contiguous float32 array of n_groups * 12 elements")
+        rc = self._L.sas_set_link_poses(self._ctx, q.shape[0], q.ctypes.data, p.ctypes.data, out.ctypes.data if out is not None else None)
+        if rc != 0:
+            self._check(rc, "sas_set_link_poses")
+        return out
+
+    @_locked
+    def get_group_poses(self) -> np.ndarray:
+        out = np.zeros((self.n_groups, 12), np.float32)
+        self._check(self._L.sas_get_group_poses(self._ctx, self.n_groups, out.ctypes.data), "sas_get_group_poses")
+        return out
 
     # -- frames -----------------------------------------------------------------------------
     _SHAPES = {"rgb": (3, torch.float32), "alpha": (1, torch.float32), "depth": (1, torch.float32),
@@ -129,6 +181,7 @@ class Rasterizer:
             a = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(count)
         return a
 
+    @_locked
     def render(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
                background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb", "alpha", "depth"),
                depth_fill_max: bool = False, fast_exp: bool = False, timing: bool = False, block: bool = True,
@@ -168,6 +221,7 @@ class Rasterizer:
         self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
+    @_locked
     def render_rgbd(self, viewmat: ArrayLike, K: ArrayLike, width: int, height: int,
                     background: Sequence[float] = (0.0, 0.0, 0.0), *, max_depth: Optional[float] = 1.0,
                     depth_fill_max: bool = True) -> Dict[str, torch.Tensor]:
@@ -195,14 +249,29 @@ class Rasterizer:
         res["mask"] = mask8.view(torch.bool)
         return res
 
+    def _pose_sets(self, pose_sets, pose_set, C: int):
+        """(Rt [S,G,12] float32, index [C] int32) of per-view pose sets, validated."""
+        Rt = np.ascontiguousarray(np.asarray(pose_sets.cpu() if isinstance(pose_sets, torch.Tensor) else pose_sets, dtype=np.float32))
+        if self.n_groups <= 0 or Rt.size % (12 * self.n_groups):
+            raise ValueError(f"pose_sets must be [S,{self.n_groups},12] for this scene")
+        Rt = Rt.reshape(-1, self.n_groups, 12)
+        idx = np.ascontiguousarray(np.asarray(pose_set, dtype=np.int32).reshape(-1))
+        if idx.shape[0] != C:
+            raise ValueError(f"pose_set must name one pose set per view ({C}), got {idx.shape[0]}")
+        return Rt, idx
+
+    @_locked
     def render_batch(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
                      background: Sequence[float] = (0.0, 0.0, 0.0), *, want: Iterable[str] = ("rgb",),
                      depth_fill_max: bool = False, block: bool = True, time_tiles: bool = False,
-                     out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                     out: Optional[Dict[str, torch.Tensor]] = None, pose_sets: Optional[ArrayLike] = None,
+                     pose_set: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
         """Render C same-sized views in one C-ABI call: ``viewmats [C,4,4]``, ``Ks [C,3,3]`` ->
         tensors ``[C,H,W,...]`` (the per-camera loop of the reference, splat_env_wrapper.py:147-158).
         Views are projected two per pass over the scene.  ``block=False`` only enqueues (results valid
-        after ``wait()``); ``out`` supplies the ``[C,H,W,...]`` output tensors."""
+        after ``wait()``); ``out`` supplies the ``[C,H,W,...]`` output tensors.  ``pose_sets [S,G,12]`` +
+        ``pose_set [C]``: view v is rendered with the group poses ``pose_sets[pose_set[v]]`` (vectorised envs:
+        sas_render_batch_posed)."""
         C = int(np.asarray(viewmats).shape[0]) if not isinstance(viewmats, torch.Tensor) else int(viewmats.shape[0])
         V = self._host_f32(viewmats, 16 * C)
         Kc = self._host_f32(Ks, 9 * C)
@@ -222,15 +291,22 @@ class Rasterizer:
         flags = (_capi.SAS_DEPTH_FILL_MAX if depth_fill_max else 0) | (0 if block else _capi.SAS_ASYNC) | \
                 (_capi.SAS_TIME_TILES if time_tiles else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._L.sas_render_batch(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
-                                      ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
+        if pose_sets is not None:
+            Rt, idx = self._pose_sets(pose_sets, pose_set, C)
+            rc = self._L.sas_render_batch_posed(self._ctx, C, V.ctypes.data, Kc.ctypes.data, idx.ctypes.data, Rt.shape[0], Rt.ctypes.data,
+                                                W, H, bg.ctypes.data, flags, ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
+        else:
+            rc = self._L.sas_render_batch(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, flags,
+                                          ptrs["rgb"], ptrs["alpha"], ptrs["depth"], ptrs["rgb8"], stream)
         if rc != 0:
             self._check(rc, "sas_render_batch")
         self._keep = [] if block else (self._keep + [(res, V, Kc, bg)])[-4:]
         return res
 
+    @_locked
     def render_batch_host(self, viewmats: ArrayLike, Ks: ArrayLike, width: int, height: int,
-                          background: Sequence[float] = (0.0, 0.0, 0.0), *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          background: Sequence[float] = (0.0, 0.0, 0.0), *, out: Optional[torch.Tensor] = None,
+                          pose_sets: Optional[ArrayLike] = None, pose_set: Optional[Sequence[int]] = None) -> torch.Tensor:
         """C same-sized views as uint8 frames ON THE HOST (sas_render_batch_host): a pinned ``[C,H,W,3]`` uint8 CPU
         tensor, filled on the frames' own streams right behind the tile kernels -- what Door B's ``get_render``
         hands out (np.uint8 arrays), without a second round trip for the device-to-host copy.  ``out`` supplies the
@@ -246,16 +322,23 @@ class Rasterizer:
         elif out.shape != (C, H, W, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device.type != "cpu":
             raise ValueError(f"out must be a contiguous uint8 CPU tensor {(C, H, W, 3)}")
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._L.sas_render_batch_host(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, 0,
-                                           out.data_ptr(), stream)
+        if pose_sets is not None:
+            Rt, idx = self._pose_sets(pose_sets, pose_set, C)
+            rc = self._L.sas_render_batch_host_posed(self._ctx, C, V.ctypes.data, Kc.ctypes.data, idx.ctypes.data, Rt.shape[0],
+                                                     Rt.ctypes.data, W, H, bg.ctypes.data, 0, out.data_ptr(), stream)
+        else:
+            rc = self._L.sas_render_batch_host(self._ctx, C, V.ctypes.data, Kc.ctypes.data, W, H, bg.ctypes.data, 0,
+                                               out.data_ptr(), stream)
         if rc != 0:
             self._check(rc, "sas_render_batch_host")
         return out
 
+    @_locked
     def wait(self) -> None:
         self._check(self._L.sas_wait(self._ctx), "sas_wait")
         self._keep = []
 
+    @_locked
     def frames_completed(self) -> Tuple[int, int]:
         """(submitted, completed) frame counts since creation (sas_frames_completed): frames
         ``0 .. completed-1`` are final and the current stream is ordered behind them."""
@@ -264,11 +347,13 @@ class Rasterizer:
         return int(sub.value), int(com.value)
 
     # -- introspection ------------------------------------------------------------------------
+    @_locked
     def stage_times(self) -> Dict[str, float]:
         ms = (ctypes.c_float * len(_capi.STAGE_NAMES))()
         self._check(self._L.sas_stage_times(self._ctx, ms, len(_capi.STAGE_NAMES)), "sas_stage_times")
         return dict(zip(_capi.STAGE_NAMES, [float(x) for x in ms]))
 
+    @_locked
     def stage_time_means(self, reset: bool = True):
         """(mean ms per stage, frames) over the timed frames completed since the last reset."""
         ms = (ctypes.c_float * len(_capi.STAGE_NAMES))()
@@ -277,11 +362,13 @@ class Rasterizer:
                     "sas_stage_time_means")
         return dict(zip(_capi.STAGE_NAMES, [float(x) for x in ms])), int(nf.value)
 
+    @_locked
     def stats(self) -> Dict[str, int]:
         st = (ctypes.c_int64 * len(_capi.STAT_NAMES))()
         self._check(self._L.sas_frame_stats(self._ctx, st, len(_capi.STAT_NAMES)), "sas_frame_stats")
         return dict(zip(_capi.STAT_NAMES, [int(x) for x in st]))
 
+    @_locked
     def read_projection(self) -> Dict[str, np.ndarray]:
         n = self.n
         radii = np.zeros((n, 2), np.int32)
@@ -294,6 +381,7 @@ class Rasterizer:
                     "sas_read_projection")
         return dict(radii=radii, means2d=means2d, depths=depths, conics=conics, colors=colors)
 
+    @_locked
     def read_tile_lists(self, tiles: int) -> Dict[str, np.ndarray]:
         m = self.stats()["n_isect"]
         off = np.zeros((tiles + 1,), np.int32)

@@ -7,42 +7,64 @@ HIP scene; their poses go to the GPU as one [G,12] block per frame.
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
-from .poses import quat_wxyz_to_matrix, quats_wxyz_to_matrices
+from .poses import matrix_to_quat_wxyz, quat_wxyz_to_matrix, quats_wxyz_to_matrices
 from .rasterizer import Rasterizer
 
 DEFAULT_VERTICAL_FOV = float(np.deg2rad(75.0))   # the reference never passes a FOV; viser uses the client's
 
 
 class GaussianSplatHandle:
-    """What ``add_gaussian_splats`` returns: a group whose pose can be reassigned every step."""
+    """What ``add_gaussian_splats`` returns: a group whose pose can be reassigned every step.  The scene keeps all
+    group poses in one float32 ``[G,3,4]`` block (what goes to the GPU); a handle writes its row when it is assigned and
+    reads it back when the poses were last set by the library's own link algebra (``SplatScene.set_link_poses``)."""
 
     def __init__(self, scene: "SplatScene", name: str, index: int, wxyz, position):
         self._scene, self.name, self.index = scene, name, index
         self._wxyz = np.asarray(wxyz, dtype=np.float64)
         self._position = np.asarray(position, dtype=np.float64)
+        self._gen = scene._links_gen
+
+    def _refresh(self) -> None:
+        if self._gen != self._scene._links_gen:       # the block was rewritten by set_link_poses since
+            row = self._scene._Rt[self.index].astype(np.float64)
+            self._wxyz, self._position = matrix_to_quat_wxyz(row[:, :3]), row[:, 3].copy()
+            self._gen = self._scene._links_gen
+
+    def _write_row(self) -> None:
+        sc = self._scene
+        sc._Rt[self.index, :, :3] = quat_wxyz_to_matrix(self._wxyz)
+        sc._Rt[self.index, :, 3] = self._position
+        sc._poses_dirty = True
 
     @property
     def wxyz(self) -> np.ndarray:
+        self._refresh()
         return self._wxyz
 
     @wxyz.setter
     def wxyz(self, v) -> None:
-        self._wxyz = np.asarray(v, dtype=np.float64)
-        self._scene._poses_dirty = True
+        with self._scene.lock:
+            self._refresh()
+            self._wxyz = np.asarray(v, dtype=np.float64)
+            self._write_row()
 
     @property
     def position(self) -> np.ndarray:
+        self._refresh()
         return self._position
 
     @position.setter
     def position(self, v) -> None:
-        self._position = np.asarray(v, dtype=np.float64)
-        self._scene._poses_dirty = True
+        with self._scene.lock:
+            self._refresh()
+            self._position = np.asarray(v, dtype=np.float64)
+            self._write_row()
 
 
 class _Camera:
@@ -53,14 +75,24 @@ class _Camera:
 
 
 class SplatScene:
-    """Registered splat groups + the renderer (plays both ``server.scene`` and the client)."""
+    """Registered splat groups + the renderer (plays both ``server.scene`` and the client).
+
+    Thread safety: ``lock`` (re-entrant) is held from the pose hand-over to the end of the render in every
+    ``get_render*`` call, by ``add_gaussian_splats`` and by the handles' setters, so a viewer thread
+    (``ViserBridge`` camera callbacks) and ``env.step`` on another thread (examples/demo_hw_splat.py:113-136 steps from
+    a ROS2 callback) serialise on one scene instead of entering the C context together; a caller that assigns several
+    handles as one update (``SplatHandler.draw_handler``) takes the lock around the whole update."""
 
     def __init__(self, device=0, background: Sequence[float] = (0.0, 0.0, 0.0)):
+        self.lock = threading.RLock()
         self._raster = Rasterizer(device)
         self._groups: List[Dict[str, np.ndarray]] = []
         self._handles: List[GaussianSplatHandle] = []
         self._uploaded = False
         self._poses_dirty = True
+        self._Rt = np.zeros((0, 3, 4), np.float32)     # all group poses, the block that goes to the GPU
+        self._links_gen = 0                            # bumped when set_link_poses rewrites the block
+        self._link_consts = None
         self.background = tuple(background)
         self.camera = _Camera()
 
@@ -68,18 +100,42 @@ class SplatScene:
                             position=(0.0, 0.0, 0.0)) -> GaussianSplatHandle:
         c = np.ascontiguousarray(np.asarray(centers, dtype=np.float32).reshape(-1, 3))
         n = c.shape[0]
-        if len(self._groups) >= 256:
-            raise RuntimeError("at most 256 splat groups")
-        self._groups.append(dict(
-            centers=c,
-            covariances=np.asarray(covariances, dtype=np.float32).reshape(n, 3, 3),
-            rgbs=np.asarray(rgbs, dtype=np.float32).reshape(n, 3),
-            opacities=np.asarray(opacities, dtype=np.float32).reshape(n)))
-        h = GaussianSplatHandle(self, name, len(self._handles), wxyz, position)
-        self._handles.append(h)
-        self._uploaded = False
-        self._poses_dirty = True
+        with self.lock:
+            if len(self._groups) >= 256:
+                raise RuntimeError("at most 256 splat groups")
+            self._groups.append(dict(
+                centers=c,
+                covariances=np.asarray(covariances, dtype=np.float32).reshape(n, 3, 3),
+                rgbs=np.asarray(rgbs, dtype=np.float32).reshape(n, 3),
+                opacities=np.asarray(opacities, dtype=np.float32).reshape(n)))
+            h = GaussianSplatHandle(self, name, len(self._handles), wxyz, position)
+            self._handles.append(h)
+            row = np.zeros((1, 3, 4), np.float32)
+            self._Rt = np.concatenate([self._Rt, row], axis=0)
+            h._write_row()
+            self._uploaded = False
+            self._poses_dirty = True
         return h
+
+    # -- the draw message's pose algebra inside the library (SplatHandler.draw_handler's fast path) ---------------
+    def set_link_constants(self, scale: float, Ri, ti, Rfk, tfk, weld=None, groups=None) -> None:
+        """See ``Rasterizer.set_link_constants``; kept and re-applied whenever the scene is uploaded again."""
+        with self.lock:
+            self._link_consts = (float(scale), np.array(Ri, np.float64), np.array(ti, np.float64), np.array(Rfk, np.float64),
+                                 np.array(tfk, np.float64), None if weld is None else np.array(weld, np.float64),
+                                 None if groups is None else np.array(groups, np.int32))
+            if self._uploaded:
+                self._raster.set_link_constants(*self._link_consts)
+
+    def set_link_poses(self, q_msg, p_msg) -> None:
+        """The first k links' message poses -> their groups' poses (sas_set_link_poses: float64 in C, the arithmetic of
+        ``poses.link_splat_poses`` + the quaternion round trip of the handles); the other groups keep theirs."""
+        with self.lock:
+            if self._link_consts is None:
+                raise RuntimeError("set_link_constants first")
+            self._sync()                                    # scene + whatever the handles were assigned since
+            self._raster.set_link_poses(q_msg, p_msg, out=self._Rt.reshape(-1))
+            self._links_gen += 1
 
     # -- internals ---------------------------------------------------------------------------
     def _sync(self) -> None:
@@ -95,11 +151,10 @@ class SplatScene:
                                     sh_degree=-1, group_id=gid, n_groups=len(self._groups))
             self._uploaded = True
             self._poses_dirty = True
+            if self._link_consts is not None and self._groups:
+                self._raster.set_link_constants(*self._link_consts)
         if self._poses_dirty and self._groups:
-            Rt = np.empty((len(self._handles), 3, 4), dtype=np.float32)
-            Rt[:, :, :3] = quats_wxyz_to_matrices(np.stack([h.wxyz for h in self._handles]))
-            Rt[:, :, 3] = np.stack([h.position for h in self._handles])
-            self._raster.set_group_poses(Rt.reshape(-1, 12))
+            self._raster.set_group_poses(self._Rt.reshape(-1, 12))
         self._poses_dirty = False
 
     @staticmethod
@@ -129,25 +184,29 @@ class SplatScene:
     # -- client side ---------------------------------------------------------------------------
     def get_render(self, height: int, width: int, wxyz=None, position=None, fov: Optional[float] = None) -> np.ndarray:
         """uint8 [H,W,3] frame from a camera pose (camera-to-world, OpenCV axes)."""
-        self._sync()
         wxyz = self.camera.wxyz if wxyz is None else wxyz
         position = self.camera.position if position is None else position
         V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))
-        return self._raster.render_batch_host(V[None], K[None], int(width), int(height), self.background).numpy()[0]
+        with self.lock:
+            self._sync()
+            return self._raster.render_batch_host(V[None], K[None], int(width), int(height), self.background).numpy()[0]
 
     def get_renders(self, height: int, width: int, cam_poses, fov: Optional[float] = None) -> np.ndarray:
         """uint8 [C,H,W,3] for C same-sized cameras ``[(wxyz, position), ...]`` in one batched call."""
-        self._sync()
         f = self.camera.fov if fov is None else float(fov)
         Vs, Ks = self._views_and_Ks(int(height), int(width), np.stack([np.asarray(w, dtype=np.float64) for w, _ in cam_poses]),
                                     [p for _, p in cam_poses], f)
-        # frames land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
-        return self._raster.render_batch_host(Vs, Ks, int(width), int(height), self.background).numpy()
+        with self.lock:
+            self._sync()
+            # frames land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
+            return self._raster.render_batch_host(Vs, Ks, int(width), int(height), self.background).numpy()
 
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
-        self._sync()
         V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))
-        return self._raster.render(V, K, int(width), int(height), self.background, want=("rgb", "alpha", "depth"))
+        with self.lock:
+            self._sync()
+            return self._raster.render(V, K, int(width), int(height), self.background, want=("rgb", "alpha", "depth"))
 
     def close(self) -> None:
-        self._raster.close()
+        with self.lock:
+            self._raster.close()

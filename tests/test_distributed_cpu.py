@@ -150,3 +150,40 @@ def test_step_pipeline_gathers_only_completed_steps(lag, n_bufs):
     assert violations == []
     want = [(s, [100.0 * s, 100.0 * s + 1.0]) for s in range(n_steps)] * 2
     assert seen == want
+
+
+# ---- bench.py --gpus N launches its own ranks ----------------------------------------------------------------------
+def _bench(args, env_extra=None, timeout=240):
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, str(root / "bench.py"), *args], capture_output=True, text=True, env=env, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must run TWO ranks (it used to print n_gpus: 1): the parent
+    starts torch.distributed.run itself; the stand-in renderer (--dry-run, gloo) exercises sharding and the gather."""
+    rc, line, err = _bench(["--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["dry_run"] and line["gather_ok"] and line["gathered_steps"] == 5
+    assert line["config"]["views_per_step"] == 4          # weak scaling: two views per rank
+
+
+def test_bench_world_size_must_match_gpus():
+    rc, line, err = _bench(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=1" in err
+
+
+def test_bench_gather_with_a_world_that_does_not_divide_the_views():
+    """Config 4 (8 views) on 3 ranks: every rank's gather payload is ceil(8 / 3) = 3 frames (dist.gather needs one
+    shape on all ranks), ranks with fewer views pad."""
+    rc, line, err = _bench(["--gpus", "3", "--dry-run", "--config", "4", "--steps", "3", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 3 and line["gather_ok"] and line["config"]["views_per_step"] == 8

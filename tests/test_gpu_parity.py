@@ -290,13 +290,18 @@ def test_background_enters_linearly_at_full_size(rasterizer):
     assert np.abs((r1["rgb"] - r0["rgb"]) - w)[free].max() <= 2e-7 * 4
 
 
-def test_config5_view_5m_gaussians(rasterizer):
-    """One 1080p view of config 5 (5M Gaussians): long lists, every sort class, HBM-heavy projection."""
+def test_config5_all_four_views_5m_gaussians(rasterizer):
+    """Config 5 (5M Gaussians, four 1080p views): long lists, every sort class, HBM-heavy projection.  One view with
+    the full set of outputs, then all four as one batch (two view pairs) against the oracle."""
     sc, cams = config_scene_and_cameras(5)
     _upload(rasterizer, sc)
     _compare(rasterizer, sc, cams[1])
     st = rasterizer.stats()
     assert st["n_isect"] > 10_000_000 and st["max_tile_len"] > 16384
+    batch = rasterizer.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 1920, 1080, BG, want=("rgb",))
+    for v, cam in enumerate(cams):
+        ref = oracle.render_scene(sc, cam, background=BG)
+        assert np.array_equal(batch["rgb"][v].cpu().numpy(), ref["rgb"]), v
 
 
 @pytest.mark.parametrize("name", TWIN_CASES)
@@ -772,3 +777,93 @@ def test_randomised_edge_cases(rasterizer, seed):
         got = out[k].cpu().numpy()
         assert np.abs(got.astype(np.float64) - ref[k]).max() <= (1 if k == "rgb8" else 1e-4), k
         assert np.array_equal(got, ref[k]), k
+
+
+def test_quad_layout_crowded_bucket_with_a_wide_depth_range(monkeypatch):
+    """The quad layout's complete-ordering path on a tile whose keys span a WIDE depth range (so that the four
+    workgroups of the tile really do bucket, scan minima / maxima and take the bail decision from the key segment)
+    while one depth bucket is crowded (3 000 coplanar splats): the key segment stays read-only for all four -- quadrant
+    0 orders storage slots in the id segment by the projection's depth words -- so every quadrant takes the same
+    decision and only quadrant 0 writes the tile.  Several frames in flight, twice, so that siblings are dispatched
+    at different times."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    from sim_a_splat_amd.synthetic import SyntheticScene
+    monkeypatch.setenv("SAS_QUAD", "1")
+    rng = np.random.default_rng(77)
+    n_plane, n_rest = 3000, 3000
+    sc = make_scene(n_plane + n_rest, seed=612, log_scale_mean=float(np.log(0.03)))
+    sc.means[:n_plane, 2] = 0.25                                              # one crowded depth
+    sc.means[:n_plane, :2] = rng.uniform(-0.35, 0.35, size=(n_plane, 2)).astype(np.float32)
+    sc.means[n_plane:] = np.stack([rng.uniform(-0.5, 0.5, n_rest), rng.uniform(-0.5, 0.5, n_rest), rng.uniform(-2.5, 2.0, n_rest)], 1).astype(np.float32)
+    sc.opacities[:] = np.clip(sc.opacities, 0.004, 0.03)                      # nothing saturates: every list is walked to its end
+    r = Rasterizer("cuda:0")
+    try:
+        _upload(r, sc)
+        cam = ring_camera(64, 48, 60.0)
+        _compare(r, sc, cam, depth_fill=True)
+        st = r.stats()
+        assert st["fallback_tiles"] > 0 and st["quad_layout"] == 1 and st["max_tile_len"] > 1024
+        ref = oracle.render_scene(sc, cam, background=BG)
+        outs = [torch.empty((48, 64, 3), device="cuda:0") for _ in range(4)]
+        for rep in range(2):
+            for i in range(4):
+                r.render(cam.viewmat, cam.K, 64, 48, BG, want=("rgb",), out={"rgb": outs[i]}, block=False)
+            r.wait()
+            for i in range(4):
+                assert np.array_equal(outs[i].cpu().numpy(), ref["rgb"]), (rep, i)
+    finally:
+        r.close()
+
+
+def test_radius_beyond_16_bits_reads_back_whole(rasterizer):
+    """A camera inside a large, close Gaussian: projected radii beyond 65 535 pixels (z = 0.02, fx = 2000).  The
+    parity hook reports them whole (they used to be packed in 16 bits each); the image is unaffected either way."""
+    from sim_a_splat_amd.synthetic import SyntheticScene, Camera, intrinsics
+    means = np.array([[0.0, 0.0, 0.02], [0.3, 0.1, 1.0]], np.float32)
+    sc = SyntheticScene(means=means, quats=np.array([[1, 0, 0, 0], [1, 0, 0, 0]], np.float32),
+                        scales=np.array([[0.5, 0.5, 0.001], [0.05, 0.05, 0.05]], np.float32), opacities=np.array([0.9, 0.8], np.float32),
+                        sh=np.zeros((2, 16, 3), np.float32), sh_degree=3)
+    sc.sh[:, 0] = 1.0
+    cam = Camera(np.eye(4, dtype=np.float32), intrinsics(2000.0, 2000.0, 32.0, 24.0), 64, 48)
+    _upload(rasterizer, sc)
+    _, ref = _compare(rasterizer, sc, cam)
+    proj = rasterizer.read_projection()
+    assert ref["radii"].max() > 65535
+    assert np.array_equal(proj["radii"], ref["radii"])
+
+
+def test_per_view_pose_sets_of_vectorised_envs(rasterizer):
+    """sas_render_batch_posed: four envs, each with its OWN link poses, two cameras per env, one call; every frame
+    equals the oracle's frame of that env's poses (splat_env_wrapper.py:121-159 poses the scene per env).  Also through
+    the host-delivery form, and with sas_set_group_poses in between without disturbing frames in flight."""
+    G, E = 6, 4
+    sc = make_scene(30000, seed=808, log_scale_mean=float(np.log(0.03)), n_groups=G)
+    _upload(rasterizer, sc, group_id=sc.group_id, n_groups=G)
+    sets = np.stack([random_group_poses(G, seed=300 + e, max_angle=0.6, max_shift=0.25) for e in range(E)])
+    cams = [ring_camera(160, 120, 130.0, yaw_deg=20.0), ring_camera(160, 120, 130.0, yaw_deg=140.0, elev=0.5)]
+    Vs = np.stack([cams[v % 2].viewmat for v in range(2 * E)])
+    Ks = np.stack([cams[v % 2].K for v in range(2 * E)])
+    idx = [v // 2 for v in range(2 * E)]
+    refs = [oracle.render(sc.means, sc.opacities, sc.sh, cams[v % 2].viewmat, cams[v % 2].K, 160, 120, quats=sc.quats, scales=sc.scales,
+                          sh_degree=3, group_id=sc.group_id, group_Rt=sets[v // 2], background=BG, want_rgb8=True) for v in range(2 * E)]
+    assert not np.array_equal(refs[0]["rgb"], refs[2]["rgb"])                  # the envs really differ
+    rasterizer.set_group_poses(random_group_poses(G, seed=999))               # the context's own poses: not used by posed views
+    out = rasterizer.render_batch(Vs, Ks, 160, 120, BG, want=("rgb", "rgb8"), pose_sets=sets, pose_set=idx)
+    for v in range(2 * E):
+        assert np.array_equal(out["rgb"][v].cpu().numpy(), refs[v]["rgb"]), v
+        assert np.array_equal(out["rgb8"][v].cpu().numpy(), refs[v]["rgb8"]), v
+    host = rasterizer.render_batch_host(Vs, Ks, 160, 120, BG, pose_sets=sets, pose_set=idx)
+    for v in range(2 * E):
+        assert np.array_equal(host[v].numpy(), refs[v]["rgb8"]), v
+    # a pose update while frames are in flight: the frames keep the poses they were submitted with
+    outs = []
+    for e in range(E):
+        rasterizer.set_group_poses(sets[e])
+        outs.append(rasterizer.render(cams[0].viewmat, cams[0].K, 160, 120, BG, want=("rgb",), block=False))
+    rasterizer.set_group_poses(random_group_poses(G, seed=5))
+    rasterizer.wait()
+    for e in range(E):
+        assert np.array_equal(outs[e]["rgb"].cpu().numpy(), refs[2 * e]["rgb"]), e
+    with pytest.raises(Exception):
+        rasterizer.render_batch(Vs, Ks, 160, 120, BG, pose_sets=sets, pose_set=[9] * (2 * E))
