@@ -37,6 +37,7 @@ class SwingingArmEnv:
     def __init__(self):
         self.t = 0
         self._names = [f"plant::link{i}" for i in range(N_LINKS)]
+        self._cycle = {}     # draw messages by time step (the stand-in is not what this demo measures)
 
     def reset(self, seed=None, reset_to_state=None):
         self.t = 0
@@ -53,10 +54,17 @@ class SwingingArmEnv:
 
     def _generate_draw_msg(self):
         """lcmt_viewer_draw-shaped message (num_links, robot_num, link_name, quaternion wxyz, position)."""
+        key = self.t % 512                                            # a 512-step cycle of the swing
+        msg = self._cycle.get(key)
+        if msg is None:
+            msg = self._cycle[key] = self._make_msg(key)
+        return msg
+
+    def _make_msg(self, t):
         i = np.arange(N_LINKS)
-        half = 0.15 * np.sin(0.05 * self.t + i)                      # rotation by 2 * half about z: (cos, 0, 0, sin)
+        half = 0.15 * np.sin(0.05 * t + i)                           # rotation by 2 * half about z: (cos, 0, 0, sin)
         q = np.stack([np.cos(half), np.zeros(N_LINKS), np.zeros(N_LINKS), np.sin(half)], axis=1)
-        p = np.stack([0.02 * np.sin(0.03 * self.t + i), np.zeros(N_LINKS), np.zeros(N_LINKS)], axis=1)
+        p = np.stack([0.02 * np.sin(0.03 * t + i), np.zeros(N_LINKS), np.zeros(N_LINKS)], axis=1)
         return types.SimpleNamespace(num_links=N_LINKS, robot_num=[3] * N_LINKS, quaternion=q.tolist(), position=p.tolist(),
                                      link_name=self._names)
 
@@ -66,7 +74,7 @@ class SwingingArmEnv:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--save", type=str, default="")
     a = ap.parse_args()
 
@@ -85,7 +93,7 @@ def main():
     })
     env.reset()
     obs = None
-    for _ in range(10):                                                # warm-up
+    for _ in range(600):                                               # warm-up (and one cycle of the stand-in's messages)
         obs, *_ = env.step(None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -111,6 +111,25 @@ int sas_set_link_constants(sas_ctx *ctx, int n_links, double scale, const double
                            const double *tfk, const double *weld, const int *group);
 int sas_set_link_poses(sas_ctx *ctx, int k_links, const double *q_msg, const double *p_msg, float *Rt_out);
 int sas_get_group_poses(sas_ctx *ctx, int n_groups, float *Rt);
+/* Camera riding on a link (SplatHandler.get_attached_frame, splat_handler.py:316-332) with the context's ICP
+ * similarity: pose = icp o SE3(q_link, (p_link + local_xyz) * s) -- the local offset is ADDED in world axes, as the
+ * reference does.  Outputs: unit quaternion wxyz [4] and position [3] of the camera-to-world pose. */
+int sas_link_attached_frame(sas_ctx *ctx, const double *q_link, const double *p_link, const double *local_xyz,
+                            double *wxyz_out, double *xyz_out);
+
+/* The same algebra as pure functions (no context, no GPU; float64 in, what the GPU gets out): the CPU tests hold them
+ * against the NumPy forms of sim_a_splat_amd/poses.py.
+ *   sas_link_group_poses   k link message poses -> Rt_out [k,12] float32 (the expression of sas_set_link_constants)
+ *   sas_attached_frame     as sas_link_attached_frame with the similarity given
+ *   sas_camera_matrices    n camera-to-world poses (wxyz [n,4] any norm, position [n,3], OpenCV axes) + vertical field of
+ *                          view -> viewmats [n,16] and Ks [n,9] float32: V = [R^T | -R^T p], f = (H/2) / tan(fov/2),
+ *                          principal point at the image centre (what get_render's camera means) */
+int sas_link_group_poses(int k_links, double scale, const double *Ri, const double *ti, const double *Rfk, const double *tfk,
+                         const double *weld, const double *q_msg, const double *p_msg, float *Rt_out);
+int sas_attached_frame(double scale, const double *Ri, const double *ti, const double *q_link, const double *p_link,
+                       const double *local_xyz, double *wxyz_out, double *xyz_out);
+int sas_camera_matrices(int n, const double *wxyz, const double *position, double fov, int width, int height,
+                        float *viewmats, float *Ks);
 
 /*
  * Render one view.  Serves get_outputs_for_camera (Door A) and get_render (Door B).
@@ -180,6 +199,12 @@ int sas_render_batch_posed(sas_ctx *ctx, int n_views, const float *viewmats, con
 int sas_render_batch_host_posed(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, const int *pose_set,
                                 int n_sets, const float *Rt, int width, int height, const float *background,
                                 unsigned flags, uint8_t *rgb8_host, void *stream);
+
+/* sas_render_batch_host from camera POSES: n_views camera-to-world poses (wxyz [n,4], position [n,3], float64, OpenCV
+ * axes: what client.get_render(height, width, wxyz, position) takes, splat_env_wrapper.py:148-157) and one vertical
+ * field of view; the view matrices and intrinsics are those of sas_camera_matrices. */
+int sas_render_cameras_host(sas_ctx *ctx, int n_views, const double *wxyz, const double *position, double fov, int width,
+                            int height, const float *background, unsigned flags, uint8_t *rgb8_host, void *stream);
 
 /* Complete every SAS_ASYNC frame in flight: synchronise with each, and where its intersection buffer
  * overflowed grow it and render the frame again. */

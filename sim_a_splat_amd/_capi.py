@@ -27,7 +27,7 @@ STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "wi
 
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (
-    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_set_link_constants", "sas_set_link_poses", "sas_get_group_poses", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_render_batch_host", "sas_render_batch_posed", "sas_render_batch_host_posed", "sas_wait", "sas_frames_completed",
+    "sas_create", "sas_destroy", "sas_scene_upload", "sas_set_group_poses", "sas_set_link_constants", "sas_set_link_poses", "sas_get_group_poses", "sas_link_attached_frame", "sas_link_group_poses", "sas_attached_frame", "sas_camera_matrices", "sas_render_cameras_host", "sas_render", "sas_render_rgbd", "sas_render_batch", "sas_render_batch_host", "sas_render_batch_posed", "sas_render_batch_host_posed", "sas_wait", "sas_frames_completed",
     "sas_last_error", "sas_stage_times", "sas_stage_time_means", "sas_frame_stats", "sas_read_projection", "sas_read_tile_lists",
     "sas_version",
 )
@@ -57,6 +57,12 @@ def lib() -> ctypes.CDLL:
     L.sas_set_link_constants.argtypes = [vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp]
     L.sas_set_link_poses.argtypes = [vp, ci, vp, vp, vp]
     L.sas_get_group_poses.argtypes = [vp, ci, vp]
+    cd = ctypes.c_double
+    L.sas_link_attached_frame.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sas_link_group_poses.argtypes = [ci, cd, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sas_attached_frame.argtypes = [cd, vp, vp, vp, vp, vp, vp, vp]
+    L.sas_camera_matrices.argtypes = [ci, vp, vp, cd, ci, ci, vp, vp]
+    L.sas_render_cameras_host.argtypes = [vp, ci, vp, vp, cd, ci, ci, vp, cu, vp, vp]
     L.sas_render.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]
     L.sas_render_rgbd.argtypes = [vp, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp, vp, vp]
     L.sas_render_batch.argtypes = [vp, ci, vp, vp, ci, ci, vp, cu, vp, vp, vp, vp, vp]

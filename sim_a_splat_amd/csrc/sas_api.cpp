@@ -862,6 +862,88 @@ int sas_set_link_constants(sas_ctx *c, int n_links, double scale, const double *
     return SAS_OK;
 }
 
+// ---- pure host functions (no context, no GPU): the float64 pose / camera algebra, testable on any machine ----------
+int sas_link_group_poses(int k_links, double scale, const double *Ri, const double *ti, const double *Rfk, const double *tfk,
+                         const double *weld, const double *q_msg, const double *p_msg, float *Rt_out)
+{
+    if (k_links < 0 || (k_links > 0 && (!Ri || !ti || !Rfk || !tfk || !q_msg || !p_msg || !Rt_out))) return SAS_ERR_INVALID;
+    const double w0[3] = {0, 0, 0};
+    const double *wd = weld ? weld : w0;
+    for (int k = 0; k < k_links; ++k) {
+        double Rm[9], RmF[9], T1[9], R[9], q[4], Rq[9];
+        quat_to_matrix(q_msg + 4 * k, Rm);
+        const double tm[3] = {p_msg[3 * k] + wd[0], p_msg[3 * k + 1] + wd[1], p_msg[3 * k + 2] + wd[2]};
+        mul33(Rm, Rfk + 9 * (size_t)k, true, RmF);    // Rm Rfk^T
+        mul33(Ri, RmF, false, T1);
+        mul33(T1, Ri, true, R);                        // R = Ri Rm Rfk^T Ri^T
+        // t = ti - R ti + s (tm - RmF tfk) Ri^T
+        double u[3], t[3];
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j) acc += RmF[3 * r + j] * tfk[3 * (size_t)k + j];
+            u[r] = scale * (tm[r] - acc);
+        }
+        for (int r = 0; r < 3; ++r) {
+            double rti = 0.0, uri = 0.0;
+            for (int j = 0; j < 3; ++j) rti += R[3 * r + j] * ti[j];
+            for (int j = 0; j < 3; ++j) uri += u[j] * Ri[3 * r + j];
+            t[r] = (ti[r] - rti) + uri;
+        }
+        matrix_to_quat(R, q);        // what the handle stores ...
+        quat_to_matrix(q, Rq);       // ... and what the scene uploads
+        float *dst = Rt_out + 12 * (size_t)k;
+        for (int r = 0; r < 3; ++r) {
+            for (int j = 0; j < 3; ++j) dst[4 * r + j] = (float)Rq[3 * r + j];
+            dst[4 * r + 3] = (float)t[r];
+        }
+    }
+    return SAS_OK;
+}
+
+int sas_attached_frame(double scale, const double *Ri, const double *ti, const double *q_link, const double *p_link,
+                       const double *local_xyz, double *wxyz_out, double *xyz_out)
+{
+    if (!Ri || !ti || !q_link || !p_link || !local_xyz || !wxyz_out || !xyz_out) return SAS_ERR_INVALID;
+    double Rl[9], R[9];
+    quat_to_matrix(q_link, Rl);
+    mul33(Ri, Rl, false, R);
+    const double p[3] = {(p_link[0] + local_xyz[0]) * scale, (p_link[1] + local_xyz[1]) * scale, (p_link[2] + local_xyz[2]) * scale};
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < 3; ++j) acc += Ri[3 * r + j] * p[j];
+        xyz_out[r] = acc + ti[r];
+    }
+    matrix_to_quat(R, wxyz_out);
+    return SAS_OK;
+}
+
+int sas_camera_matrices(int n, const double *wxyz, const double *position, double fov, int width, int height, float *viewmats,
+                        float *Ks)
+{
+    if (n < 0 || (n > 0 && (!wxyz || !position || !viewmats || !Ks))) return SAS_ERR_INVALID;
+    const double f = 0.5 * height / std::tan(0.5 * fov);      // vertical FOV, square pixels
+    for (int c = 0; c < n; ++c) {
+        double R[9];
+        quat_to_matrix(wxyz + 4 * c, R);                        // camera-to-world, OpenCV axes
+        float *V = viewmats + 16 * (size_t)c;
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                V[4 * r + j] = (float)R[3 * j + r];             // R^T
+                acc += R[3 * j + r] * position[3 * c + j];
+            }
+            V[4 * r + 3] = (float)(-acc);
+        }
+        V[12] = V[13] = V[14] = 0.0f;
+        V[15] = 1.0f;
+        float *K = Ks + 9 * (size_t)c;
+        K[0] = (float)f; K[1] = 0.0f; K[2] = (float)(0.5 * width);
+        K[3] = 0.0f; K[4] = (float)f; K[5] = (float)(0.5 * height);
+        K[6] = 0.0f; K[7] = 0.0f; K[8] = 1.0f;
+    }
+    return SAS_OK;
+}
+
 int sas_set_link_poses(sas_ctx *c, int k_links, const double *q_msg, const double *p_msg, float *Rt_out)
 {
     if (!c) return SAS_ERR_INVALID;
@@ -869,36 +951,21 @@ int sas_set_link_poses(sas_ctx *c, int k_links, const double *q_msg, const doubl
     const LinkConsts &L = c->links;
     if (k_links < 0 || k_links > L.n) return fail(c, SAS_ERR_INVALID, "%d link poses, constants for %d (sas_set_link_constants)", k_links, L.n);
     if (k_links > 0 && (!q_msg || !p_msg)) return fail(c, SAS_ERR_INVALID, "q_msg and p_msg are required");
-    for (int k = 0; k < k_links; ++k) {
-        double Rm[9], RmF[9], T1[9], R[9], q[4], Rq[9];
-        quat_to_matrix(q_msg + 4 * k, Rm);
-        const double tm[3] = {p_msg[3 * k] + L.weld[0], p_msg[3 * k + 1] + L.weld[1], p_msg[3 * k + 2] + L.weld[2]};
-        mul33(Rm, &L.Rfk[9 * (size_t)k], true, RmF);    // Rm Rfk^T
-        mul33(L.Ri, RmF, false, T1);
-        mul33(T1, L.Ri, true, R);                        // R = Ri Rm Rfk^T Ri^T
-        // t = ti - R ti + s (tm - RmF tfk) Ri^T
-        double u[3], t[3];
-        for (int r = 0; r < 3; ++r) {
-            double acc = 0.0;
-            for (int j = 0; j < 3; ++j) acc += RmF[3 * r + j] * L.tfk[3 * (size_t)k + j];
-            u[r] = L.scale * (tm[r] - acc);
-        }
-        for (int r = 0; r < 3; ++r) {
-            double rti = 0.0, uri = 0.0;
-            for (int j = 0; j < 3; ++j) rti += R[3 * r + j] * L.ti[j];
-            for (int j = 0; j < 3; ++j) uri += u[j] * L.Ri[3 * r + j];
-            t[r] = (L.ti[r] - rti) + uri;
-        }
-        matrix_to_quat(R, q);        // what the handle stores ...
-        quat_to_matrix(q, Rq);       // ... and what the scene uploads
-        float *dst = &c->group_host[12 * (size_t)L.group[(size_t)k]];
-        for (int r = 0; r < 3; ++r) {
-            for (int j = 0; j < 3; ++j) dst[4 * r + j] = (float)Rq[3 * r + j];
-            dst[4 * r + 3] = (float)t[r];
-        }
-    }
+    float rows[12 * 256];
+    if (k_links > 0)
+        sas_link_group_poses(k_links, L.scale, L.Ri, L.ti, L.Rfk.data(), L.tfk.data(), L.weld, q_msg, p_msg, rows);
+    for (int k = 0; k < k_links; ++k) memcpy(&c->group_host[12 * (size_t)L.group[(size_t)k]], rows + 12 * k, sizeof(float) * 12);
     if (Rt_out && !c->group_host.empty()) memcpy(Rt_out, c->group_host.data(), sizeof(float) * c->group_host.size());
     return SAS_OK;
+}
+
+int sas_link_attached_frame(sas_ctx *c, const double *q_link, const double *p_link, const double *local_xyz, double *wxyz_out,
+                            double *xyz_out)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (c->links.n <= 0) return fail(c, SAS_ERR_INVALID, "sas_set_link_constants first (the ICP similarity)");
+    const int rc = sas_attached_frame(c->links.scale, c->links.Ri, c->links.ti, q_link, p_link, local_xyz, wxyz_out, xyz_out);
+    return rc ? fail(c, rc, "sas_link_attached_frame: null argument") : SAS_OK;
 }
 
 int sas_get_group_poses(sas_ctx *c, int n_groups, float *Rt)
@@ -1139,6 +1206,17 @@ int sas_render_batch_host_posed(sas_ctx *c, int n_views, const float *viewmats, 
     ps.pose_set = pose_set; ps.n_sets = n_sets; ps.Rt = Rt;
     if (!Rt) return fail(c, SAS_ERR_INVALID, "sas_render_batch_host_posed: Rt is required");
     return render_batch_host_impl(c, n_views, viewmats, Ks, width, height, background, flags, rgb8_host, stream, ps);
+}
+
+int sas_render_cameras_host(sas_ctx *c, int n_views, const double *wxyz, const double *position, double fov, int width,
+                            int height, const float *background, unsigned flags, uint8_t *rgb8_host, void *stream)
+{
+    if (!c) return SAS_ERR_INVALID;
+    if (n_views <= 0) return n_views == 0 ? SAS_OK : fail(c, SAS_ERR_INVALID, "bad view batch");
+    if (!wxyz || !position || !(fov > 0.0)) return fail(c, SAS_ERR_INVALID, "camera poses and a positive field of view are required");
+    std::vector<float> V((size_t)16 * n_views), K((size_t)9 * n_views);
+    sas_camera_matrices(n_views, wxyz, position, fov, width, height, V.data(), K.data());
+    return render_batch_host_impl(c, n_views, V.data(), K.data(), width, height, background, flags, rgb8_host, stream, PoseSets());
 }
 
 int sas_wait(sas_ctx *c)

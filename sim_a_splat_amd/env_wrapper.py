@@ -103,7 +103,9 @@ class SplatEnvWrapper:
         try:
             for info in self.moving_cameras_info.values():
                 wxyz, xyz = self.splat_handler.get_attached_frame(info["link_name"], info["local_frame"], msg)
-                moving_camera_poses.append(poses.SE3(wxyz_xyz=np.concatenate((wxyz, xyz))))
+                v = np.empty(7)
+                v[:4], v[4:] = wxyz, xyz
+                moving_camera_poses.append(poses.SE3(wxyz_xyz=v))
         except AttributeError as e:
             logging.error(f"Error getting moving camera poses: {e}. Have you configured the cameras with _configure_cameras?")
         return moving_camera_poses
@@ -125,7 +127,7 @@ class SplatEnvWrapper:
         obs = self.unwrapped._get_obs()
         img_out = self.render()
         for ii in range(len(img_out)):
-            img_out[ii] = np.moveaxis(img_out[ii], -1, 0)
+            img_out[ii] = img_out[ii].transpose(2, 0, 1)       # np.moveaxis(img, -1, 0): the same view
         obs.update({f"camera_{ii}": img_out[ii] for ii in range(len(img_out))})
         return obs
 

@@ -142,13 +142,17 @@ class SplatHandler:
         """``msg``: lcmt_viewer_draw-shaped (num_links, robot_num[], position[][3], quaternion[][4] wxyz).  The
         k-th link of the robot (``robot_num == rbt_idx``, message order) drives splat group k, as in the reference
         (:227-314); all links are posed in one batch of small matrix products."""
-        idxs = [idx for idx in range(msg.num_links) if msg.robot_num[idx] == self.rbt_idx]
+        rn, rbt = msg.robot_num, self.rbt_idx
+        idxs = [idx for idx in range(msg.num_links) if rn[idx] == rbt]
         if len(idxs) > len(self.fk):
             for idx in idxs[len(self.fk):]:
                 logging.warning(f"Warning: Received draw command for non-existent Link index {idx}.")
             idxs = idxs[:len(self.fk)]
         k = min(len(idxs), 7, len(self.splat_links_handler))               # :282: at most seven link groups
         if k == 0:
+            return
+        if self._fast and idxs[k - 1] == k - 1:          # the robot's links lead the message (Drake's order): no gather
+            self.scene.set_link_poses(msg.quaternion[:k], msg.position[:k])
             return
         q = np.asarray([msg.quaternion[i] for i in idxs[:k]], dtype=np.float64)
         p = np.asarray([msg.position[i] for i in idxs[:k]], dtype=np.float64)
@@ -172,10 +176,15 @@ class SplatHandler:
     def get_attached_frame(self, body_name: str, local_frame_pos, msg) -> Tuple[np.ndarray, np.ndarray]:
         """``local_frame_pos``: the camera's ``local_frame`` (SE3-like, as the reference passes it, :316-319) or
         just its translation; only the translation is used -- added in world axes, the reference's behaviour."""
-        local_xyz = poses.pose_wxyz_xyz(local_frame_pos)[1] if (hasattr(local_frame_pos, "translation") or
-                                                                (isinstance(local_frame_pos, (tuple, list)) and len(local_frame_pos) == 2)) \
-            else np.asarray(local_frame_pos, dtype=np.float64).reshape(3)
-        idx = list(msg.link_name).index("plant::" + body_name)
+        if type(local_frame_pos) is poses.SE3:
+            local_xyz = local_frame_pos.wxyz_xyz[4:]
+        elif hasattr(local_frame_pos, "translation") or (isinstance(local_frame_pos, (tuple, list)) and len(local_frame_pos) == 2):
+            local_xyz = poses.pose_wxyz_xyz(local_frame_pos)[1]
+        else:
+            local_xyz = np.asarray(local_frame_pos, dtype=np.float64).reshape(3)
+        idx = msg.link_name.index("plant::" + body_name) if isinstance(msg.link_name, list) else list(msg.link_name).index("plant::" + body_name)
+        if self._fast and hasattr(self.scene, "attached_frame"):
+            return self.scene.attached_frame(msg.quaternion[idx], msg.position[idx], local_xyz)
         R, t = poses.attached_frame(self.scale_factor, self.Ri, self.ti, msg.quaternion[idx], msg.position[idx], local_xyz)
         return poses.matrix_to_quat_wxyz(R), t
 

@@ -12,6 +12,18 @@ from typing import Sequence, Tuple
 import numpy as np
 
 
+def mm3(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """[...,3,3] @ [...,3,3] with the products summed left to right in plain float64 operations -- what a triple loop
+    does (``sas_api.cpp`` mul33), independent of the BLAS behind ``np.matmul`` (which may fuse multiply-adds): the
+    library's C forms of this module's functions are held to it bit for bit (tests/test_host_logic.py)."""
+    return (np.asarray(A, np.float64)[..., :, :, None] * np.asarray(B, np.float64)[..., None, :, :]).sum(axis=-2)
+
+
+def mv3(A: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """[...,3,3] @ [...,3], summed left to right (see ``mm3``)."""
+    return (np.asarray(A, np.float64) * np.asarray(v, np.float64)[..., None, :]).sum(axis=-1)
+
+
 def quat_wxyz_to_matrix(q: Sequence[float]) -> np.ndarray:
     return quats_wxyz_to_matrices(np.asarray(q, dtype=np.float64).reshape(1, 4))[0]   # one arithmetic for both forms
 
@@ -96,6 +108,9 @@ class SE3:
 def pose_wxyz_xyz(pose) -> Tuple[np.ndarray, np.ndarray]:
     """(wxyz [4], xyz [3]) of a camera / frame pose given as an SE3-like object (``.rotation().wxyz`` and
     ``.translation()``: viser.transforms.SE3 or ``poses.SE3``), a ``(wxyz, xyz)`` pair, or a flat 7-vector."""
+    if type(pose) is SE3:                                  # the common case on the per-step path: no attribute probing
+        v = pose.wxyz_xyz
+        return v[:4], v[4:]
     if hasattr(pose, "rotation") and hasattr(pose, "translation"):
         rot = pose.rotation() if callable(pose.rotation) else pose.rotation
         tr = pose.translation() if callable(pose.translation) else pose.translation
@@ -160,9 +175,10 @@ def link_splat_poses(scale: float, Ri: np.ndarray, ti: np.ndarray, Rfk: np.ndarr
         R = Ri Rm Rfk^T Ri^T,   t = ti - R ti + s Ri (tm - Rm Rfk^T tfk),   tm = p_msg + weld."""
     Rm = quats_wxyz_to_matrices(q_msg)
     tm = np.asarray(p_msg, np.float64).reshape(-1, 3) + np.asarray(weld_t, np.float64)
-    RmF = Rm @ np.transpose(np.asarray(Rfk, np.float64), (0, 2, 1))            # Rm Rfk^T
-    R = Ri @ RmF @ Ri.T
-    t = ti - R @ ti + scale * (tm - np.einsum("kij,kj->ki", RmF, np.asarray(tfk, np.float64))) @ Ri.T
+    Ri, ti = np.asarray(Ri, np.float64), np.asarray(ti, np.float64)
+    RmF = mm3(Rm, np.transpose(np.asarray(Rfk, np.float64), (0, 2, 1)))        # Rm Rfk^T
+    R = mm3(mm3(Ri, RmF), Ri.T)
+    t = (ti - mv3(R, ti)) + mv3(Ri, scale * (tm - mv3(RmF, np.asarray(tfk, np.float64))))
     return R, t
 
 
@@ -171,7 +187,7 @@ def attached_frame(scale: float, Ri: np.ndarray, ti: np.ndarray, q_link: Sequenc
     """Camera pose attached to a link (splat_handler.py:316-332).  As in the reference, the local
     offset is ADDED to the link position in world axes (not rotated by the link) and then scaled."""
     p = (np.asarray(p_link, np.float64) + np.asarray(local_xyz, np.float64)) * scale
-    return Ri @ quat_wxyz_to_matrix(q_link), Ri @ p + ti
+    return mm3(Ri, quat_wxyz_to_matrix(q_link)), mv3(Ri, p) + np.asarray(ti, np.float64)
 
 
 def rt_to_row12(R: np.ndarray, t: np.ndarray) -> np.ndarray:

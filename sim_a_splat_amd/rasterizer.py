@@ -164,6 +164,17 @@ class Rasterizer:
         return out
 
     @_locked
+    def link_attached_frame(self, q_link, p_link, local_xyz) -> Tuple[np.ndarray, np.ndarray]:
+        """(wxyz, xyz) of a camera riding on a link (sas_link_attached_frame; the ICP similarity of set_link_constants)."""
+        a = np.empty(17, np.float64)
+        a[0:4], a[4:7], a[7:10] = q_link, p_link, local_xyz
+        base = a.ctypes.data
+        rc = self._L.sas_link_attached_frame(self._ctx, base, base + 32, base + 56, base + 80, base + 112)
+        if rc != 0:
+            self._check(rc, "sas_link_attached_frame")
+        return a[10:14], a[14:17]
+
+    @_locked
     def get_group_poses(self) -> np.ndarray:
         out = np.zeros((self.n_groups, 12), np.float32)
         self._check(self._L.sas_get_group_poses(self._ctx, self.n_groups, out.ctypes.data), "sas_get_group_poses")
@@ -331,6 +342,26 @@ class Rasterizer:
                                                out.data_ptr(), stream)
         if rc != 0:
             self._check(rc, "sas_render_batch_host")
+        return out
+
+    @_locked
+    def render_cameras_host(self, wxyz, position, fov: float, width: int, height: int,
+                            background: Sequence[float] = (0.0, 0.0, 0.0), *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``render_batch_host`` from camera-to-world POSES (``wxyz [C,4]``, ``position [C,3]``, OpenCV axes) and a vertical
+        field of view: the view matrices and intrinsics are computed inside the library (sas_render_cameras_host)."""
+        q = np.ascontiguousarray(np.asarray(wxyz, dtype=np.float64).reshape(-1, 4))
+        p = np.ascontiguousarray(np.asarray(position, dtype=np.float64).reshape(-1, 3))
+        C, W, H = q.shape[0], int(width), int(height)
+        bg = self._host_f32(background, 3)
+        if out is None:
+            out = torch.empty((C, H, W, 3), dtype=torch.uint8, pin_memory=True)
+        elif out.shape != (C, H, W, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device.type != "cpu":
+            raise ValueError(f"out must be a contiguous uint8 CPU tensor {(C, H, W, 3)}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._L.sas_render_cameras_host(self._ctx, C, q.ctypes.data, p.ctypes.data, float(fov), W, H, bg.ctypes.data, 0,
+                                             out.data_ptr(), stream)
+        if rc != 0:
+            self._check(rc, "sas_render_cameras_host")
         return out
 
     @_locked

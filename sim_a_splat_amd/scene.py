@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .poses import matrix_to_quat_wxyz, quat_wxyz_to_matrix, quats_wxyz_to_matrices
+from .poses import matrix_to_quat_wxyz, mv3, quat_wxyz_to_matrix, quats_wxyz_to_matrices
 from .rasterizer import Rasterizer
 
 DEFAULT_VERTICAL_FOV = float(np.deg2rad(75.0))   # the reference never passes a FOV; viser uses the client's
@@ -162,7 +162,7 @@ class SplatScene:
         R = quat_wxyz_to_matrix(wxyz)                      # camera-to-world, OpenCV axes (+z forward, +y down)
         V = np.eye(4)
         V[:3, :3] = R.T
-        V[:3, 3] = -R.T @ np.asarray(position, dtype=np.float64)
+        V[:3, 3] = -mv3(R.T, np.asarray(position, dtype=np.float64))
         f = 0.5 * height / np.tan(0.5 * fov)               # vertical FOV, square pixels
         K = np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]])
         return V.astype(np.float32), K.astype(np.float32)
@@ -175,7 +175,7 @@ class SplatScene:
         V = np.zeros((C, 4, 4))
         Rt = np.transpose(R, (0, 2, 1))
         V[:, :3, :3] = Rt
-        V[:, :3, 3] = -np.stack([Rt[c] @ np.asarray(position[c], dtype=np.float64) for c in range(C)])
+        V[:, :3, 3] = -mv3(Rt, np.asarray(position, dtype=np.float64).reshape(C, 3))
         V[:, 3, 3] = 1.0
         f = 0.5 * height / np.tan(0.5 * fov)
         K = np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]])
@@ -186,20 +186,33 @@ class SplatScene:
         """uint8 [H,W,3] frame from a camera pose (camera-to-world, OpenCV axes)."""
         wxyz = self.camera.wxyz if wxyz is None else wxyz
         position = self.camera.position if position is None else position
-        V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))
         with self.lock:
             self._sync()
-            return self._raster.render_batch_host(V[None], K[None], int(width), int(height), self.background).numpy()[0]
+            # view matrix and intrinsics inside the library (sas_camera_matrices: the arithmetic of _view_and_K)
+            return self._raster.render_cameras_host(wxyz, position, self.camera.fov if fov is None else float(fov), int(width), int(height),
+                                                    self.background).numpy()[0]
 
     def get_renders(self, height: int, width: int, cam_poses, fov: Optional[float] = None) -> np.ndarray:
         """uint8 [C,H,W,3] for C same-sized cameras ``[(wxyz, position), ...]`` in one batched call."""
         f = self.camera.fov if fov is None else float(fov)
-        Vs, Ks = self._views_and_Ks(int(height), int(width), np.stack([np.asarray(w, dtype=np.float64) for w, _ in cam_poses]),
-                                    [p for _, p in cam_poses], f)
+        C = len(cam_poses)
+        qp = np.empty((2, C, 4), np.float64)               # wxyz rows, then xyz rows (padded): one allocation
+        for c, (w, p) in enumerate(cam_poses):
+            qp[0, c] = w
+            qp[1, c, :3] = p
         with self.lock:
             self._sync()
-            # frames land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
-            return self._raster.render_batch_host(Vs, Ks, int(width), int(height), self.background).numpy()
+            # view matrices and intrinsics inside the library (sas_camera_matrices: the arithmetic of _views_and_Ks); frames
+            # land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
+            return self._raster.render_cameras_host(qp[0], qp[1, :, :3], f, int(width), int(height), self.background).numpy()
+
+    def attached_frame(self, q_link, p_link, local_xyz):
+        """(wxyz, xyz) of a camera riding on a link, with the similarity of ``set_link_constants`` (sas_link_attached_frame)."""
+        with self.lock:
+            if self._link_consts is None:
+                raise RuntimeError("set_link_constants first")
+            self._sync()
+            return self._raster.link_attached_frame(q_link, p_link, local_xyz)
 
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
         V, K = self._view_and_K(int(height), int(width), wxyz, position, self.camera.fov if fov is None else float(fov))
