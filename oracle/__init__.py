@@ -158,7 +158,7 @@ def render(means, opacities, colors, viewmat, K, width: int, height: int, *, qua
         conics = np.zeros((n, 3), np.float32)
         cols = np.zeros((n, 3), np.float32)
         toff = np.zeros((tiles + 1,), np.int32)
-    stats = np.zeros(2, np.int64)
+    stats = np.zeros(3, np.int64)
     if dump:
         # first call to learn M, second to fetch ids (cheap at test sizes)
         rc = L.sas_oracle_render(ctypes.byref(sc), _ptr(V), _ptr(Km), W, H, _ptr(bg), depth_mode,
@@ -173,7 +173,7 @@ def render(means, opacities, colors, viewmat, K, width: int, height: int, *, qua
                              _ptr(toff), _ptr(sids), cap, _ptr(stats))
     if rc != 0:
         raise MemoryError("oracle allocation failed")
-    out.update(rgb=rgb, alpha=alpha, depth=depth, n_visible=int(stats[0]), n_isect=int(stats[1]))
+    out.update(rgb=rgb, alpha=alpha, depth=depth, n_visible=int(stats[0]), n_isect=int(stats[1]), n_isect_tight=int(stats[2]))
     if want_rgb8:
         out["rgb8"] = rgb8
     if dump:

@@ -32,7 +32,7 @@ static int run(int n, int W, int H, int groups, int degree)
     int tiles = ((W + 15) / 16) * ((H + 15) / 16);
     int32_t *rad = malloc(sizeof(int32_t) * 2 * (n + 1)), *toff = malloc(sizeof(int32_t) * (tiles + 1));
     float *m2 = malloc(sizeof(float) * 2 * (n + 1)), *dep = malloc(sizeof(float) * (n + 1)), *con = malloc(sizeof(float) * 3 * (n + 1)), *cc = malloc(sizeof(float) * 3 * (n + 1));
-    int64_t st[2];
+    int64_t st[3];
     int rc = sas_oracle_render(&s, V, K, W, H, bg, 1, rgb, a, d, r8, rad, m2, dep, con, cc, toff, NULL, 0, st);
     int32_t *ids = malloc(sizeof(int32_t) * (st[1] + 1));
     rc |= sas_oracle_render(&s, V, K, W, H, bg, 0, rgb, NULL, d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, ids, st[1], st);

@@ -249,6 +249,7 @@ typedef struct {
     float ca, cb, cc;        /* conic */
     float rgb[3];
     float opac;
+    float thr;               /* ln(255 opacity) + 1e-3: no pixel with sigma above it can reach alpha >= 1/255 */
 } proj_t;
 
 /* T1 + T2 for one Gaussian */
@@ -337,7 +338,8 @@ static void project_one(const sas_oracle_scene *s, const cam_t *c, int64_t i, pr
 
     float op = s->opacities[i];
     if (op < OC_ALPHA_THRESHOLD) return;
-    float extent = fminf(3.33f, sqrtf(2.0f * sas_oracle_logf(op / OC_ALPHA_THRESHOLD)));
+    float lnq = sas_oracle_logf(op / OC_ALPHA_THRESHOLD);
+    float extent = fminf(3.33f, sqrtf(2.0f * lnq));
     float b = 0.5f * (c00 + c11);
     float tmp = sqrtf(fmaxf(0.01f, fmaf(b, b, -det)));
     float v1 = b + tmp;
@@ -351,6 +353,7 @@ static void project_one(const sas_oracle_scene *s, const cam_t *c, int64_t i, pr
     o->mx = mx; o->my = my; o->depth = z;
     o->ca = ca; o->cb = cb; o->cc = ccn;
     o->opac = op;
+    o->thr = lnq + 1e-3f;
     if (o->rx <= 0 || o->ry <= 0) return; /* colour mask of gsplat.rasterization: (radii > 0).all(-1) */
     if (s->sh_degree >= 0) {
         int K = (s->sh_degree + 1) * (s->sh_degree + 1);
@@ -374,6 +377,41 @@ static inline void tile_rect(const proj_t *p, const cam_t *c, int *x0, int *x1, 
     *x1 = (int)fminf(fmaxf(fx1, 0.0f), tw);
     *y0 = (int)fminf(fmaxf(fy0, 0.0f), th);
     *y1 = (int)fminf(fmaxf(fy1, 0.0f), th);
+}
+
+/* Tight tiles (the product's binning; the image does not depend on it).  gsplat bins a Gaussian into every tile of its
+ * bounding rectangle; the product skips the tiles none of whose pixel centres can reach alpha >= 1/255, i.e. where the
+ * minimum of sigma over the rectangle spanned by the tile's pixel centres exceeds thr + 0.05.  For a mean outside that
+ * rectangle the minimum of the convex quadratic lies on an edge facing the mean (at most two), at the clamped
+ * stationary point of the edge.  Same operations in the same order as tile_reached() of csrc/sas_device.h: the tight
+ * intersection count (stats[2]) is compared with the product's n_isect exactly. */
+typedef struct { float mx, my, A, B, C, lim, nba, nbc; } reach_t;
+
+static inline reach_t reach_of(const proj_t *p)
+{
+    reach_t g = {p->mx, p->my, p->ca, p->cb, p->cc, p->thr + 0.05f, -p->cb / p->ca, -p->cb / p->cc};
+    return g;
+}
+
+static inline int tile_reached(const reach_t *g, int tx, int ty)
+{
+    const float x0 = (float)(tx * OC_TILE) + 0.5f, y0 = (float)(ty * OC_TILE) + 0.5f;
+    const float dx0 = x0 - g->mx, dx1 = (x0 + 15.0f) - g->mx, dy0 = y0 - g->my, dy1 = (y0 + 15.0f) - g->my;
+    const int in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;
+    if (in_x && in_y) return 1;
+    const float hA = 0.5f * g->A, hC = 0.5f * g->C;
+    float best = INFINITY;
+    if (!in_x) {
+        const float dx = dx0 > 0.0f ? dx0 : dx1;
+        const float dy = fminf(fmaxf(g->nbc * dx, dy0), dy1);
+        best = fmaf(g->B * dx, dy, fmaf(hC * dy, dy, (hA * dx) * dx));
+    }
+    if (!in_y) {
+        const float dy = dy0 > 0.0f ? dy0 : dy1;
+        const float dx = fminf(fmaxf(g->nba * dy, dx0), dx1);
+        best = fminf(best, fmaf(g->B * dx, dy, fmaf(hA * dx, dx, (hC * dy) * dy)));
+    }
+    return !(best > g->lim);
 }
 
 static int cmp_u64(const void *a, const void *b)
@@ -475,7 +513,8 @@ static inline void blend_pixel_variant(int variant, const proj_t *P, const int32
  * Full frame.  depth_mode: 0 = expected depth ED = acc_d / max(alpha,1e-10) (gsplat "RGB+ED");
  *              1 = nerfstudio fill, where(alpha > 0, ED, max(ED)).
  * Optional outputs may be NULL.  Projection dumps are [n]-sized; tile_offsets is [tiles+1];
- * sorted_ids receives at most sorted_cap entries.  stats = {n_visible, n_intersections}.
+ * sorted_ids receives at most sorted_cap entries.  stats = {n_visible, n_intersections (gsplat's rectangles),
+ * n_intersections of the tight binning}.
  * Returns 0, or -1 on allocation failure.
  */
 int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const float K[9], int W, int H,
@@ -495,14 +534,18 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) project_one(s, &c, i, &P[i]);
 
-    int64_t n_vis = 0;
+    int64_t n_vis = 0, m_tight = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (P[i].rx <= 0 || P[i].ry <= 0) continue; /* gsplat isect_tiles: radius_x <= 0 || radius_y <= 0 */
         ++n_vis;
         int x0, x1, y0, y1;
         tile_rect(&P[i], &c, &x0, &x1, &y0, &y1);
+        const reach_t rg = reach_of(&P[i]);
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) tcount[ty * c.tw + tx + 1]++;
+            for (int tx = x0; tx < x1; ++tx) {
+                tcount[ty * c.tw + tx + 1]++;
+                m_tight += tile_reached(&rg, tx, ty);
+            }
     }
     for (int t = 0; t < tiles; ++t) tcount[t + 1] += tcount[t];
     const int64_t M = tcount[tiles];
@@ -595,7 +638,7 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         int64_t m = M < sorted_cap ? M : sorted_cap;
         memcpy(o_sorted_ids, ids, sizeof(int32_t) * (size_t)m);
     }
-    if (stats) { stats[0] = n_vis; stats[1] = M; }
+    if (stats) { stats[0] = n_vis; stats[1] = M; stats[2] = m_tight; }
     free(P); free(tcount); free(keys); free(ids); free(cursor); free(tc_all);
     return 0;
 }

@@ -112,14 +112,15 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 constexpr int kSmallRect = 8;
 
 template <typename F>
-DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, F emit)
+DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, bool tight, const TileReach &tr, F emit)
 {
     const int lane = threadIdx.x & 63;
     const int w = x1 - x0;
     const int area = active ? w * (y1 - y0) : 0;
     if (area > 0 && area <= kSmallRect) {
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) emit(ty * tw + tx, v0, v1);
+            for (int tx = x0; tx < x1; ++tx)
+                if (!tight || tile_reached(tr, tx, ty)) emit(ty * tw + tx, v0, v1);
     }
     unsigned long long big = __ballot(area > kSmallRect);
     while (big) {
@@ -128,7 +129,14 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
         const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
         const int bw = __shfl(w, src), ba = __shfl(area, src);
         const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
-        for (int i = lane; i < ba; i += 64) emit((by0 + i / bw) * tw + bx0 + i % bw, b0, b1);
+        TileReach br;
+        br.mx = __shfl(tr.mx, src); br.my = __shfl(tr.my, src);
+        br.A = __shfl(tr.A, src); br.B = __shfl(tr.B, src); br.C = __shfl(tr.C, src);
+        br.lim = __shfl(tr.lim, src); br.nba = __shfl(tr.nba, src); br.nbc = __shfl(tr.nbc, src);
+        for (int i = lane; i < ba; i += 64) {
+            const int tx = bx0 + i % bw, ty = by0 + i / bw;
+            if (!tight || tile_reached(br, tx, ty)) emit(ty * tw + tx, b0, b1);
+        }
     }
 }
 
@@ -260,12 +268,15 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    const bool tight = f.tight != 0;
+    const TileReach tr = vis ? tile_reach_of(g.mx, g.my, g.ca, g.cb, g.ccn, g.thr) : TileReach{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
         __syncthreads();
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
+                    if (tight && !tile_reached(tr, tx, ty)) continue;
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
                 }
@@ -278,7 +289,7 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u, tight, tr,
                   [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_count[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
@@ -675,12 +686,20 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    // the same reach test on the same floats as the projection's count (its record), hence the same tiles
+    const bool tight = f.tight != 0;
+    TileReach tr{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+    if (tight && vis) {
+        const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
+        tr = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
+    }
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
         __syncthreads();
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
+                    if (tight && !tile_reached(tr, tx, ty)) continue;
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (SAS_IN(b, kHistBins, 111)) atomicAdd(&s_hist[b], 1);
                 }
@@ -695,6 +714,7 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
+                    if (tight && !tile_reached(tr, tx, ty)) continue;
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (!SAS_IN(b, kHistBins, 113)) continue;
                     const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
@@ -704,7 +724,7 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
                 }
     }
     const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, tight, tr, [&](int tile, unsigned lo, unsigned hi) {
         if (!SAS_IN(tile, f.n_tiles, 115)) return;
         const int pos = atomicAdd(&f.tile_cursor[tile], 1);
         if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;

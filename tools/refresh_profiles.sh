@@ -34,5 +34,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IN
 # SQ counter groups of the tile kernel on isolated frames
 bash tools/pmc_tile.sh > $out/tile_sq_counters.txt 2>&1
 SAS_LIB_PATH=variants/lib_stats.so python tools/blend_stats.py 3 > $out/blend_stats.txt 2>&1
-{ tools/microbench/pk_f32_rate | head -9; tools/microbench/clock_probe; } > $out/microbench.txt 2>&1
+# the issue-rate microbenchmarks are built here from their sources (no binaries in the tree)
+for mb in pk_f32_rate clock_probe; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench/$mb.hip -o /tmp/$mb || exit 1
+done
+{ /tmp/pk_f32_rate | head -9; /tmp/clock_probe; } > $out/microbench.txt 2>&1
 tail -c 700 $out/bench.json
