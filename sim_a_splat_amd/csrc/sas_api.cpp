@@ -115,7 +115,7 @@ struct sas_ctx {
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
     // cameras) in groups that share one set of launches (grid.y = view).  SAS_GROUP=1 disables, 2..4 sets the size.
     int group_views = -1;           // -1: half of the slots (two groups can be in flight)
-    bool tight_tiles = true;        // SAS_TIGHT=0: bin by gsplat's bounding rectangle (A/B measurements)
+    bool tight_tiles = false;       // SAS_TIGHT=1: bin only the tiles of gsplat's rectangle the footprint reaches (measured: no gain)
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
@@ -619,11 +619,6 @@ int sas_create(int device, sas_ctx **out)
         if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
     }
     if (const char *e = getenv("SAS_TIGHT")) c->tight_tiles = atoi(e) != 0;
-    if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
-    if (const char *e = getenv("SAS_QUAD_TILES")) {
-        const int v = atoi(e);
-        if (v >= 0) c->quad_max_tiles = v;
-    }
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&sl.poses_host, sizeof(float) * 12 * 256) == hipSuccess;

@@ -672,37 +672,58 @@ __global__ __launch_bounds__(256) void k_host_copy(SasHostCopy h)
 // single returning global atomic, then rank inside the run with LDS atomics.  Key = depth bits << 32
 // | storage slot; the rare runs of identical depth are ordered by the caller's index (perm[slot])
 // when a tile is sorted, exactly as the reference's stable sort orders them.
+#ifndef SAS_TUNE_SCATTER_GPT
+#define SAS_TUNE_SCATTER_GPT 1
+#endif
+constexpr int kScatterGpt = SAS_TUNE_SCATTER_GPT;   // Gaussians per thread: a workgroup bins 256 * GPT storage-order neighbours
+
+template <int GPT>
 DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
 {
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
     __shared__ int s_base[kHistBins];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint4 inf = make_uint4(0u, 0u, 0u, 0u);
-    if (i < s.n) inf = f.info[i];
-    const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
-    const bool vis = x1 > x0 && y1 > y0;
-    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
-    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
-    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
-    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
-    // the same reach test on the same floats as the projection's count (its record), hence the same tiles
     const bool tight = f.tight != 0;
-    TileReach tr{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-    if (tight && vis) {
-        const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
-        tr = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
+    int x0[GPT], x1[GPT], y0[GPT], y1[GPT];
+    bool vis[GPT], in_win[GPT];
+    unsigned long long key[GPT];
+    TileReach tr[GPT];
+    int ux0 = 0x7fffffff, uy0 = 0x7fffffff, ux1 = 0, uy1 = 0;
+    bool any_in = false;
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+        const int64_t i = ((int64_t)blockIdx.x * GPT + g) * 256 + threadIdx.x;
+        uint4 inf = make_uint4(0u, 0u, 0u, 0u);
+        if (i < s.n) inf = f.info[i];
+        x0[g] = inf.x & 0xffff; x1[g] = inf.x >> 16; y0[g] = inf.y & 0xffff; y1[g] = inf.y >> 16;
+        vis[g] = x1[g] > x0[g] && y1[g] > y0[g];
+        key[g] = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
+        const int rect_area = vis[g] ? (x1[g] - x0[g]) * (y1[g] - y0[g]) : 0;
+        in_win[g] = rect_area > 0 && rect_area <= kWinRect;
+        if (in_win[g]) {
+            ux0 = min(ux0, x0[g]); uy0 = min(uy0, y0[g]); ux1 = max(ux1, x1[g]); uy1 = max(uy1, y1[g]);
+            any_in = true;
+        }
+        // the same reach test on the same floats as the projection's count (its record), hence the same tiles
+        tr[g] = TileReach{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+        if (tight && vis[g]) {
+            const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
+            tr[g] = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
+        }
     }
+    const Window w = wg_window(any_in, ux0, ux1, uy0, uy1, s_win);
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
         __syncthreads();
-        if (in_win)
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) {
-                    if (tight && !tile_reached(tr, tx, ty)) continue;
-                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
-                    if (SAS_IN(b, kHistBins, 111)) atomicAdd(&s_hist[b], 1);
-                }
+#pragma unroll
+        for (int g = 0; g < GPT; ++g)
+            if (in_win[g])
+                for (int ty = y0[g]; ty < y1[g]; ++ty)
+                    for (int tx = x0[g]; tx < x1[g]; ++tx) {
+                        if (tight && !tile_reached(tr[g], tx, ty)) continue;
+                        const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                        if (SAS_IN(b, kHistBins, 111)) atomicAdd(&s_hist[b], 1);
+                    }
         __syncthreads();
         for (int b = threadIdx.x; b < w.area; b += 256) {
             const int cnt = s_hist[b];
@@ -711,28 +732,33 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
             s_hist[b] = 0;
         }
         __syncthreads();
-        if (in_win)
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) {
-                    if (tight && !tile_reached(tr, tx, ty)) continue;
-                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
-                    if (!SAS_IN(b, kHistBins, 113)) continue;
-                    const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
-                    // pos >= cap is the documented overflow path (the frame is rendered again); a position
-                    // beyond the tile's own segment would be a bug
-                    if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key;
-                }
+#pragma unroll
+        for (int g = 0; g < GPT; ++g)
+            if (in_win[g])
+                for (int ty = y0[g]; ty < y1[g]; ++ty)
+                    for (int tx = x0[g]; tx < x1[g]; ++tx) {
+                        if (tight && !tile_reached(tr[g], tx, ty)) continue;
+                        const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                        if (!SAS_IN(b, kHistBins, 113)) continue;
+                        const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
+                        // pos >= cap is the documented overflow path (the frame is rendered again); a position
+                        // beyond the tile's own segment would be a bug
+                        if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key[g];
+                    }
     }
-    const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, tight, tr, [&](int tile, unsigned lo, unsigned hi) {
-        if (!SAS_IN(tile, f.n_tiles, 115)) return;
-        const int pos = atomicAdd(&f.tile_cursor[tile], 1);
-        if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
-    });
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+        const unsigned klo = (unsigned)key[g], khi = (unsigned)(key[g] >> 32);
+        for_each_tile(vis[g] && !(w.fits && in_win[g]), x0[g], x1[g], y0[g], y1[g], tw, klo, khi, tight, tr[g], [&](int tile, unsigned lo, unsigned hi) {
+            if (!SAS_IN(tile, f.n_tiles, 115)) return;
+            const int pos = atomicAdd(&f.tile_cursor[tile], 1);
+            if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
+        });
+    }
 }
 
-__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body(s, tw, f); }
-__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body<kScatterGpt>(s, tw, f); }
+__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body<kScatterGpt>(s, tw, mf.f[blockIdx.y]); }
 
 }  // namespace
 
@@ -795,7 +821,7 @@ void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti 
 void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf)
 {
     if (s.n <= 0) return;
-    hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 255) / 256), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
+    hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 256 * kScatterGpt - 1) / (256 * kScatterGpt)), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
 }
 
 void sas_launch_pose_upload(hipStream_t st, const SasPoseUpload &u)
@@ -828,7 +854,7 @@ void sas_launch_host_copy(hipStream_t st, const SasHostCopy &h)
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f)
 {
     if (s.n <= 0) return;
-    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    const unsigned grid = (unsigned)((s.n + 256 * kScatterGpt - 1) / (256 * kScatterGpt));
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, tw, f);
 }
 
