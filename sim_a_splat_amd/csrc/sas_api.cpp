@@ -43,7 +43,7 @@ struct RenderArgs {
 
 // Per-frame scratch.  Every slot owns one, so several frames can be on the GPU at the same time.
 struct Scratch {
-    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, tilemax;
+    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, wgbase, tilemax;
     long long cap = 0;
     bool counters_zero = false;   // the counter block is known to be all zero (SasFrame invariant)
 };
@@ -252,11 +252,14 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     SasFrame f{};
     f.rec = (float4 *)q.rec.p;
     f.info = (uint4 *)q.info.p;
-    // counters block: [tickets][8 device counters][tile_count tiles+1, zero padded]   (left zeroed by every frame)
+    // counters block: [tickets][8 device counters, 16 class cursors][tile_count][tile_big]   (left zeroed by every frame)
     f.tickets = (unsigned *)q.counters.p;
     f.stats = (unsigned *)q.counters.p + SAS_TICKET_INTS;
+    f.class_cursor = (int *)q.counters.p + SAS_TICKET_INTS + 8;
     f.stats_host = sl.stats_host;
-    f.tile_count = (int *)q.counters.p + SAS_TICKET_INTS + 8;
+    f.tile_count = (int *)q.counters.p + SAS_TICKET_INTS + 32;
+    f.tile_big = f.tile_count + sas_count_stride(tiles);
+    f.wg_base = (int *)q.wgbase.p;
     const size_t ts = sas_tile_stride(tiles);
     f.tile_offset = (int *)q.tilebuf.p;
     f.tile_cursor = (int *)q.tilebuf.p + ts;
@@ -347,6 +350,7 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
         }
     }
     if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
+    if ((rc = ensure(c, q.wgbase, sizeof(int) * SAS_WIN_BINS * (size_t)((n + 255) / 256 + 1)))) return rc;
     if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * 4 * (size_t)tiles))) return rc;   // x 4: one slot per quadrant in the quad layout
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
@@ -619,6 +623,11 @@ int sas_create(int device, sas_ctx **out)
         if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
     }
     if (const char *e = getenv("SAS_TIGHT")) c->tight_tiles = atoi(e) != 0;
+    if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("SAS_QUAD_TILES")) {
+        const int v = atoi(e);
+        if (v >= 0) c->quad_max_tiles = v;
+    }
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&sl.poses_host, sizeof(float) * 12 * 256) == hipSuccess;
@@ -661,7 +670,7 @@ int sas_destroy(sas_ctx *c)
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
-                          &sl.scr.wgvis, &sl.scr.tilemax})
+                          &sl.scr.wgvis, &sl.scr.wgbase, &sl.scr.tilemax})
             release(*b);
     }
     for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->perm, &c->host_stage}) release(*b);

@@ -46,14 +46,23 @@ struct SasScene {
 //                  end of a frame): [0] n_visible [1] n_isect [2] overflow [4] max tile length [5] window misses;
 //                  [6] tiles the lazy kernel had to order completely (one depth bucket > chunk): zeroed by the tail,
 //                  counted by the tile kernel with a system-scope atomic (rare)
-// INVARIANT: tile_count[] is all zero between frames -- the tile kernel (k_blend on the full path) clears the count of
-// the tile it has just rendered, so a frame needs no memset in front of its projection.
+// INVARIANT: tile_count[] and tile_big[] are all zero between frames -- the tile kernel (k_blend on the full path)
+// clears the counts of the tile it has just rendered, so a frame needs no memset in front of its projection.
+// Binning by RESERVATION: a projection workgroup counts its intersections per tile in an LDS window and adds each
+// window bin to tile_count with ONE returning atomic; what it gets back -- where its run starts inside the tile's
+// segment -- goes to wg_base[workgroup][bin].  k_scatter (same workgroups, same windows) then needs no global atomic
+// and no counting pass: position = tile_offset + wg_base + rank in LDS.  Gaussians outside the window scheme (large
+// rectangles) count into tile_big with one atomic per intersection and are placed behind the tile's window runs
+// through tile_cursor, as before.
 struct SasFrame {
     float4 *rec;
     uint4 *info;
-    int *tile_count;   // [tiles+1] (+ zero padding the tail's 16-byte loads may touch)
+    int *tile_count;   // [tiles] window intersections per tile (+ zero padding the tail's 16-byte loads may touch)
+    int *tile_big;     // [tiles] per-intersection counts of Gaussians outside the window scheme (same padding)
+    int *wg_base;      // [n_wg * SAS_WIN_BINS] start of each projection workgroup's run inside its tiles' segments
+    int *class_cursor; // [16] next free position in tile_order per list-length class (descending), set by the projection's tail
     int *tile_offset;  // [tiles+1]
-    int *tile_cursor;  // [tiles]
+    int *tile_cursor;  // [tiles] next free position for a tile's `big` entries: starts at tile_offset + tile_count
     int *tile_order;   // [tiles] tiles by descending list-length class (blend launch order)
     int *sort_class;   // [6] starts of the large / mid / small sort class in tile_order, tiles; then {0, tiles}
     unsigned long long *keys;  // [cap]  depth bits << 32 | storage slot
@@ -156,5 +165,8 @@ void sas_launch_depth_tail(hipStream_t st, int tiles, const SasParams &P, const 
 // size in ints of a frame's counter block ([8 statistics words][tile counts + zero padding]) and of one of the
 // three per-tile int arrays of `tilebuf` (offsets, cursors, order; 16-byte aligned strides)
 #define SAS_TICKET_INTS (65 * 32)
-static inline size_t sas_counter_ints(int tiles) { return SAS_TICKET_INTS + 8 + (((size_t)tiles + 1 + 1023) & ~(size_t)1023) + 1024; }
+#define SAS_WIN_BINS 2048   // bins of a binning workgroup's LDS window (8 KiB)
+static inline size_t sas_count_stride(int tiles) { return (((size_t)tiles + 1 + 1023) & ~(size_t)1023) + 1024; }
+// [tickets][8 statistics words + 16 class cursors + 8 pad][tile_count][tile_big]
+static inline size_t sas_counter_ints(int tiles) { return SAS_TICKET_INTS + 32 + 2 * sas_count_stride(tiles); }
 static inline size_t sas_tile_stride(int tiles) { return ((size_t)tiles + 1 + 3) & ~(size_t)3; }

@@ -146,8 +146,9 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
 // one per intersection (device-scope atomics execute at the memory side: ~10 G/s scattered).
 // Gaussians with a large rectangle stay out of the window and use the wave-cooperative walk.
 #ifndef SAS_TUNE_HIST
-#define SAS_TUNE_HIST 2048
+#define SAS_TUNE_HIST SAS_WIN_BINS
 #endif
+static_assert(SAS_TUNE_HIST <= SAS_WIN_BINS, "wg_base holds SAS_WIN_BINS entries per workgroup");
 #ifndef SAS_TUNE_WINRECT
 #define SAS_TUNE_WINRECT 64
 #endif
@@ -281,16 +282,19 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
                     if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
                 }
         __syncthreads();
+        // one RETURNING atomic per touched tile: the workgroup's run inside the tile's segment is reserved here, and
+        // k_scatter (same workgroup, same window) reads where it starts instead of reserving it itself
+        int *wb = f.wg_base + (size_t)blockIdx.x * SAS_WIN_BINS;
         for (int b = threadIdx.x; b < w.area; b += 256) {
             const int cnt = s_hist[b];
             const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
-            if (cnt && SAS_IN(tile, f.n_tiles, 102)) atomicAdd(&f.tile_count[tile], cnt);
+            wb[b] = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
         }
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
     for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u, tight, tr,
-                  [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_count[tile], 1); });
+                  [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
     if (threadIdx.x == 0) *s_nvis = 0;
@@ -302,16 +306,17 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     if (threadIdx.x == 0) __hip_atomic_store(&f.wg_vis[blockIdx.x], *s_nvis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- the projection's tail (T5): offsets, cursors, tile order, statistics ---------------------------------------
-// Run by the 256 threads of the projection's last workgroup.  Thread t owns the `per` consecutive tiles from
-// t * per (a multiple of four: 16-byte loads and stores; the count array is zero-padded past its end).  Tiles are
-// ordered by list-length class (floor(log2) + 1, 15 and up together), longest first, so that long lists start early
-// in the tile kernel and short ones fill its tail: class counts in LDS bins replicated 32 times (the lanes of a wave
-// then hit different words: same-address LDS atomics serialise -- the separate scan kernel this replaces spent most
-// of its 14 us on them), one scan over the 512 (class, copy) cells, placement by returning LDS atomics.
-// Three phases, each reading the thread's counts again (32 per 16-byte-load burst: L2 hits after the first): held in
-// registers across the phases they raised the PROJECTION's register count and cost it occupancy; a lone wave issues
-// one instruction per ~7 cycles, so the phases are written for few instructions.
+// ---- the projection's tail (T5): offsets, cursors, list-length classes, statistics -----------------------------------
+// Run by the 256 threads of the projection's last workgroup, which every later kernel of the frame waits for: written
+// for few instructions (a lone wave issues one per ~7 cycles) and few dependent memory round trips.  Thread t owns the
+// `per` consecutive tiles from t * per (a multiple of four: 16-byte loads and stores; the count arrays are zero-padded
+// past their ends).  Two phases, each reading the thread's counts (16 tiles per 16-byte-load burst: L2 hits the second
+// time): held in registers across the barrier they raised the PROJECTION's register count and cost it occupancy.
+// The tile kernel starts its long lists first: tiles are ordered by list-length class (floor(log2) + 1, 15 and up
+// together), longest first.  Here only the class SIZES are counted (LDS bins replicated 32 times: the lanes of a wave
+// then hit different words -- same-address LDS atomics serialise, the scan kernel this replaces spent most of its
+// 14 us on them) and turned into the classes' first positions (class_cursor); the tiles are put in place by the front
+// workgroups of k_scatter, off this critical path.
 DEV int len_class(int v) { return v ? min(15, 32 - __clz(v)) : 0; }
 
 DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
@@ -323,21 +328,27 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
     int *s_bins = lds + 16;   // [16 classes (descending)][32 copies]
     const int per = (((tiles + 255) >> 8) + 3) & ~3;
     const int t0 = tid * per;
-    const int4 *cnt4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
+    const int4 *win4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
+    const int4 *big4 = reinterpret_cast<const int4 *>(f.tile_big + t0);
     s_bins[tid] = 0;
     s_bins[256 + tid] = 0;
-    // ---- phase 1: totals
+    // ---- phase 1: totals (bursts of 16 tiles: 2 x 4 16-byte loads in flight, 32 registers)
     int nvis = 0;
     for (int i = tid; i < f.n_wg; i += 256) nvis += f.wg_vis[i];
     int total = 0, maxlen = 0;
-    for (int k0 = 0; k0 < per; k0 += 32) {
-        int4 c[8];
+    for (int k0 = 0; k0 < per; k0 += 16) {
+        int4 c[4], g[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const bool in = k0 + 4 * j < per;
+            c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            total += (c[j].x + c[j].y) + (c[j].z + c[j].w);
-            maxlen = max(max(maxlen, max(c[j].x, c[j].y)), max(c[j].z, c[j].w));
+        for (int j = 0; j < 4; ++j) {
+            const int sx = c[j].x + g[j].x, sy = c[j].y + g[j].y, sz = c[j].z + g[j].z, sw = c[j].w + g[j].w;
+            total += (sx + sy) + (sz + sw);
+            maxlen = max(max(maxlen, max(sx, sy)), max(sz, sw));
         }
     }
     int incl = total;
@@ -357,87 +368,71 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
     int run = incl - total;
     for (int w = 0; w < wv; ++w) run += s_w[w];
     const int carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    // ---- phase 2: offsets, scatter cursors, class counts
-    for (int k0 = 0; k0 < per; k0 += 32) {
-        int4 c[8];
+    const int maxlen_all = max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
+    const int nvis_all = s_w[8] + s_w[9] + s_w[10] + s_w[11];
+    // ---- phase 2: offsets, cursors of the `big` entries, class sizes
+    for (int k0 = 0; k0 < per; k0 += 16) {
+        int4 c[4], g[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const bool in = k0 + 4 * j < per;
+            c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int k = k0 + 4 * j, t = t0 + k;
             if (k >= per || t >= tiles) continue;
-            const int4 o = make_int4(run, run + c[j].x, run + c[j].x + c[j].y, run + c[j].x + c[j].y + c[j].z);
-            run = o.w + c[j].w;
-            const int cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+            const int cw[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+            const int cc[4] = {c[j].x + g[j].x, c[j].y + g[j].y, c[j].z + g[j].z, c[j].w + g[j].w};
+            const int4 o = make_int4(run, run + cc[0], run + cc[0] + cc[1], run + cc[0] + cc[1] + cc[2]);
+            run = o.w + cc[3];
+            const int4 cur = make_int4(o.x + cw[0], o.y + cw[1], o.z + cw[2], o.w + cw[3]);
             if (t + 3 < tiles) {
                 *reinterpret_cast<int4 *>(f.tile_offset + t) = o;
-                *reinterpret_cast<int4 *>(f.tile_cursor + t) = o;
+                *reinterpret_cast<int4 *>(f.tile_cursor + t) = cur;
             } else {
-                const int oo[4] = {o.x, o.y, o.z, o.w};
+                const int oo[4] = {o.x, o.y, o.z, o.w}, uu[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (t + q < tiles) { f.tile_offset[t + q] = oo[q]; f.tile_cursor[t + q] = oo[q]; }
+                    if (t + q < tiles) { f.tile_offset[t + q] = oo[q]; f.tile_cursor[t + q] = uu[q]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (t + q < tiles) atomicAdd(&s_bins[(15 - len_class(cc[q])) * 32 + (lane & 31)], 1);
         }
     }
-    __syncthreads();
-    {   // exclusive scan of the 512 cells, two per thread
-        const int a = s_bins[2 * tid], b = s_bins[2 * tid + 1];
-        int in2 = a + b;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(in2, d);
-            if (lane >= d) in2 += o;
-        }
-        if (lane == 63) s_w[12 + wv] = in2;
-        __syncthreads();
-        int ex = in2 - (a + b);
-        for (int w = 0; w < wv; ++w) ex += s_w[12 + w];
-        s_bins[2 * tid] = ex;
-        s_bins[2 * tid + 1] = ex + a;
+    __syncthreads();   // (also: every thread has read the cross-wave scratch of phase 1)
+    if (tid < 16) {    // size of class (15 - tid): its 32 copies
+        int sum = 0;
+        for (int k = 0; k < 32; ++k) sum += s_bins[32 * tid + k];
+        s_w[tid] = sum;
     }
     __syncthreads();
     if (tid == 0) {
-        // the full path's sort classes are class ranges, hence contiguous in tile_order
-        f.sort_class[0] = 0;                        // large: length >= 4096 (classes >= 13)
-        f.sort_class[1] = s_bins[(15 - 12) * 32];   // mid:   1024..4095     (classes 11, 12)
-        f.sort_class[2] = s_bins[(15 - 10) * 32];   // small: < 1024         (classes <= 10)
+        int start = 0;
+        for (int k = 0; k < 16; ++k) {   // descending classes: entry k = class 15 - k
+            f.class_cursor[k] = start;
+            // the full path's sort classes are class ranges, hence contiguous in tile_order
+            if (k == 3) f.sort_class[1] = start;   // mid:   1024..4095     (classes 11, 12)
+            if (k == 5) f.sort_class[2] = start;   // small: < 1024         (classes <= 10)
+            start += s_w[k];
+        }
+        f.sort_class[0] = 0;             // large: length >= 4096 (classes >= 13)
         f.sort_class[3] = tiles;
-        f.sort_class[4] = 0;                        // every tile, for the full-path blend
+        f.sort_class[4] = 0;             // every tile, for the full-path blend
         f.sort_class[5] = tiles;
         f.tile_offset[tiles] = carry;
-        unsigned *h = f.stats_host;
-        h[0] = (unsigned)(s_w[8] + s_w[9] + s_w[10] + s_w[11]);
+        unsigned *h = f.stats_host;      // the statistics, straight to pinned host memory
+        h[0] = (unsigned)nvis_all;
         h[1] = (unsigned)carry;
         h[2] = (long long)carry > f.cap ? 1u : 0u;
         h[3] = 0u;
-        h[4] = (unsigned)max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
+        h[4] = (unsigned)maxlen_all;
         h[5] = f.stats[5];
         h[6] = 0u;
         h[7] = 0u;
         f.stats[5] = 0u;
-    }
-    __syncthreads();   // the class starts above are read before the placement moves them
-    // ---- phase 3: placement
-    for (int k0 = 0; k0 < per; k0 += 32) {
-        int4 c[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = (k0 + 4 * j < per) ? cnt4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = t0 + k0 + 4 * j;
-            const int cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (k0 + 4 * j < per && t + q < tiles) {
-                    const int pos = atomicAdd(&s_bins[(15 - len_class(cc[q])) * 32 + (lane & 31)], 1);
-                    if (SAS_IN(pos, tiles, 104)) f.tile_order[pos] = t + q;
-                }
-            if ((j & 1) == 1) asm volatile("" ::: "memory");   // eight tiles at a time: do not hold 32 atomic results
-        }
     }
 }
 
@@ -672,93 +667,103 @@ __global__ __launch_bounds__(256) void k_host_copy(SasHostCopy h)
 // single returning global atomic, then rank inside the run with LDS atomics.  Key = depth bits << 32
 // | storage slot; the rare runs of identical depth are ordered by the caller's index (perm[slot])
 // when a tile is sorted, exactly as the reference's stable sort orders them.
-#ifndef SAS_TUNE_SCATTER_GPT
-#define SAS_TUNE_SCATTER_GPT 1
-#endif
-constexpr int kScatterGpt = SAS_TUNE_SCATTER_GPT;   // Gaussians per thread: a workgroup bins 256 * GPT storage-order neighbours
+// ---- k_scatter: T3 emit + tile order --------------------------------------------------------------------------
+// Binning workgroups (one per projection workgroup, same 256 Gaussians, same window): the projection has already
+// reserved this workgroup's run in every tile its window touches (wg_base), so a key's position is
+// tile_offset + wg_base + its rank among the workgroup's keys for that tile (LDS atomics): no counting pass and no
+// global atomic.  Gaussians outside the window scheme (large rectangles) take one returning atomic per intersection
+// on tile_cursor, which starts behind the tile's window runs.  Key = depth bits << 32 | storage slot; the rare runs
+// of identical depth are ordered by the caller's index (perm[slot]) when a tile is sorted, exactly as the
+// reference's stable sort orders them.
+// The FRONT workgroups of the launch (256 tiles each) put the tiles into tile_order by list-length class, longest
+// first: class sizes in LDS, one returning atomic per (workgroup, class) on the class cursors the projection's tail
+// has set to the classes' first positions.
+DEV int order_workgroups(int tiles) { return (tiles + 255) >> 8; }
 
-template <int GPT>
-DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
+DEV void order_body(const SasFrame &f, int wg)
 {
-    __shared__ int s_win[4];
-    __shared__ int s_hist[kHistBins];
-    __shared__ int s_base[kHistBins];
-    const bool tight = f.tight != 0;
-    int x0[GPT], x1[GPT], y0[GPT], y1[GPT];
-    bool vis[GPT], in_win[GPT];
-    unsigned long long key[GPT];
-    TileReach tr[GPT];
-    int ux0 = 0x7fffffff, uy0 = 0x7fffffff, ux1 = 0, uy1 = 0;
-    bool any_in = false;
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) {
-        const int64_t i = ((int64_t)blockIdx.x * GPT + g) * 256 + threadIdx.x;
-        uint4 inf = make_uint4(0u, 0u, 0u, 0u);
-        if (i < s.n) inf = f.info[i];
-        x0[g] = inf.x & 0xffff; x1[g] = inf.x >> 16; y0[g] = inf.y & 0xffff; y1[g] = inf.y >> 16;
-        vis[g] = x1[g] > x0[g] && y1[g] > y0[g];
-        key[g] = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
-        const int rect_area = vis[g] ? (x1[g] - x0[g]) * (y1[g] - y0[g]) : 0;
-        in_win[g] = rect_area > 0 && rect_area <= kWinRect;
-        if (in_win[g]) {
-            ux0 = min(ux0, x0[g]); uy0 = min(uy0, y0[g]); ux1 = max(ux1, x1[g]); uy1 = max(uy1, y1[g]);
-            any_in = true;
-        }
-        // the same reach test on the same floats as the projection's count (its record), hence the same tiles
-        tr[g] = TileReach{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-        if (tight && vis[g]) {
-            const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
-            tr[g] = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
-        }
+    __shared__ int s_cls[16 * 32];   // [class (descending)][copy]
+    __shared__ int s_cbase[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = wg * 256 + tid;
+    s_cls[tid] = 0;
+    s_cls[256 + tid] = 0;
+    int cls = 0;
+    const bool in = t < f.n_tiles;
+    if (in) cls = 15 - len_class(f.tile_count[t] + f.tile_big[t]);
+    __syncthreads();
+    int rank = 0;
+    if (in) rank = atomicAdd(&s_cls[32 * cls + (lane & 31)], 1);
+    __syncthreads();
+    if (tid < 16) {   // the class's 32 copies become starts inside the workgroup's run of that class
+        int sum = 0;
+        for (int k = 0; k < 32; ++k) { const int v = s_cls[32 * tid + k]; s_cls[32 * tid + k] = sum; sum += v; }
+        s_cbase[tid] = sum ? atomicAdd(&f.class_cursor[tid], sum) : 0;
     }
-    const Window w = wg_window(any_in, ux0, ux1, uy0, uy1, s_win);
-    if (w.fits) {
-        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < GPT; ++g)
-            if (in_win[g])
-                for (int ty = y0[g]; ty < y1[g]; ++ty)
-                    for (int tx = x0[g]; tx < x1[g]; ++tx) {
-                        if (tight && !tile_reached(tr[g], tx, ty)) continue;
-                        const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
-                        if (SAS_IN(b, kHistBins, 111)) atomicAdd(&s_hist[b], 1);
-                    }
-        __syncthreads();
-        for (int b = threadIdx.x; b < w.area; b += 256) {
-            const int cnt = s_hist[b];
-            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
-            s_base[b] = (cnt && SAS_IN(tile, f.n_tiles, 112)) ? atomicAdd(&f.tile_cursor[tile], cnt) : 0;
-            s_hist[b] = 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < GPT; ++g)
-            if (in_win[g])
-                for (int ty = y0[g]; ty < y1[g]; ++ty)
-                    for (int tx = x0[g]; tx < x1[g]; ++tx) {
-                        if (tight && !tile_reached(tr[g], tx, ty)) continue;
-                        const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
-                        if (!SAS_IN(b, kHistBins, 113)) continue;
-                        const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
-                        // pos >= cap is the documented overflow path (the frame is rendered again); a position
-                        // beyond the tile's own segment would be a bug
-                        if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key[g];
-                    }
-    }
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) {
-        const unsigned klo = (unsigned)key[g], khi = (unsigned)(key[g] >> 32);
-        for_each_tile(vis[g] && !(w.fits && in_win[g]), x0[g], x1[g], y0[g], y1[g], tw, klo, khi, tight, tr[g], [&](int tile, unsigned lo, unsigned hi) {
-            if (!SAS_IN(tile, f.n_tiles, 115)) return;
-            const int pos = atomicAdd(&f.tile_cursor[tile], 1);
-            if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
-        });
+    __syncthreads();
+    if (in) {
+        const int pos = s_cbase[cls] + s_cls[32 * cls + (lane & 31)] + rank;
+        if (SAS_IN(pos, f.n_tiles, 104)) f.tile_order[pos] = t;
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body<kScatterGpt>(s, tw, f); }
-__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body<kScatterGpt>(s, tw, mf.f[blockIdx.y]); }
+DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
+{
+    const int n_order = order_workgroups(f.n_tiles);
+    if ((int)blockIdx.x < n_order) {   // uniform per workgroup
+        order_body(f, (int)blockIdx.x);
+        return;
+    }
+    const unsigned wg = blockIdx.x - (unsigned)n_order;
+    __shared__ int s_win[4];
+    __shared__ int s_hist[kHistBins];
+    __shared__ int s_base[kHistBins];
+    const int64_t i = (int64_t)wg * 256 + threadIdx.x;
+    uint4 inf = make_uint4(0u, 0u, 0u, 0u);
+    if (i < s.n) inf = f.info[i];
+    const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
+    const bool vis = x1 > x0 && y1 > y0;
+    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
+    const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
+    const bool in_win = rect_area > 0 && rect_area <= kWinRect;
+    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    // the same reach test on the same floats as the projection's count (its record), hence the same tiles
+    const bool tight = f.tight != 0;
+    TileReach tr{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+    if (tight && vis) {
+        const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
+        tr = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
+    }
+    if (w.fits) {
+        const int *wb = f.wg_base + (size_t)wg * SAS_WIN_BINS;
+        for (int b = threadIdx.x; b < w.area; b += 256) {
+            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
+            s_base[b] = SAS_IN(tile, f.n_tiles, 112) ? f.tile_offset[tile] + wb[b] : 0;
+            s_hist[b] = 0;
+        }
+        __syncthreads();
+        if (in_win)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    if (tight && !tile_reached(tr, tx, ty)) continue;
+                    const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    if (!SAS_IN(b, kHistBins, 113)) continue;
+                    const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
+                    // pos >= cap is the documented overflow path (the frame is rendered again); a position
+                    // beyond the tile's own segment would be a bug
+                    if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key;
+                }
+    }
+    const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, tight, tr, [&](int tile, unsigned lo, unsigned hi) {
+        if (!SAS_IN(tile, f.n_tiles, 115)) return;
+        const int pos = atomicAdd(&f.tile_cursor[tile], 1);
+        if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
+    });
+}
+
+__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body(s, tw, f); }
+__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
 
 }  // namespace
 
@@ -820,8 +825,8 @@ void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti 
 
 void sas_launch_scatter_multi(hipStream_t st, const SasScene &s, int tw, const SasMulti &mf)
 {
-    if (s.n <= 0) return;
-    hipLaunchKernelGGL(k_scatter_multi, dim3((unsigned)((s.n + 256 * kScatterGpt - 1) / (256 * kScatterGpt)), (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
+    const unsigned grid = (unsigned)((mf.f[0].n_tiles + 255) / 256) + (unsigned)((s.n + 255) / 256);   // tile-order workgroups first
+    hipLaunchKernelGGL(k_scatter_multi, dim3(grid, (unsigned)mf.nv), dim3(256), 0, st, s, tw, mf);
 }
 
 void sas_launch_pose_upload(hipStream_t st, const SasPoseUpload &u)
@@ -853,8 +858,7 @@ void sas_launch_host_copy(hipStream_t st, const SasHostCopy &h)
 
 void sas_launch_scatter(hipStream_t st, const SasScene &s, int tw, const SasFrame &f)
 {
-    if (s.n <= 0) return;
-    const unsigned grid = (unsigned)((s.n + 256 * kScatterGpt - 1) / (256 * kScatterGpt));
+    const unsigned grid = (unsigned)((f.n_tiles + 255) / 256) + (unsigned)((s.n + 255) / 256);   // tile-order workgroups first
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, st, s, tw, f);
 }
 

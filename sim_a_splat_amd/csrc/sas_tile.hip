@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long lon
                               [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
         const float ED = write_pixel(o, p, inside, ix, iy, c.W);
         if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
-        if (tid == 0) f.tile_count[tile] = 0;   // the frame's counters leave the frame zeroed (SasFrame invariant)
+        if (tid == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
     }
 }
 
@@ -1435,7 +1435,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     }
     const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W);
     if (WANT_MAX) store_tile_max(f, QUAD ? 4 * tile + qd : tile, ED, s_wmax);   // QUAD: one slot per quadrant (k_depth_tail reduces 4 x tiles)
-    if (tid == 0 && qd == 0) f.tile_count[tile] = 0;   // the frame's counters leave the frame zeroed (SasFrame invariant)
+    if (tid == 0 && qd == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
 #ifdef SAS_TUNE_WGTIME
     if (tid == 0 && blockIdx.x < kDbgWgMax) {
         g_dbg_wg[3 * blockIdx.x] = t_wg0;
