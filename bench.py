@@ -303,16 +303,6 @@ def main():
             r.render(c_.viewmat, c_.K, W, H, BG, want=("rgb8",), out={"rgb8": bufs[0]["rgb8"][0]})
             per_view.append(r.stats())
         st = {k: int(round(np.mean([pv[k] for pv in per_view]))) for k in ("n_visible", "n_isect")}
-        # n_isect above is what the frame BINNED (tight tiles: the tiles of gsplat's bounding rectangle the footprint
-        # reaches).  The algorithmic bytes of SURVEY.md 8d are priced on the reference algorithm's intersections --
-        # gsplat's rectangles -- which a SAS_FULL_SORT frame counts.
-        binned = st["n_isect"]
-        rect = []
-        for c_ in cams:
-            r.render(c_.viewmat, c_.K, W, H, BG, want=("rgb8",), out={"rgb8": bufs[0]["rgb8"][0]}, full_sort=True)
-            rect.append(r.stats()["n_isect"])
-        st["n_isect"] = int(round(np.mean(rect)))
-        out_bpp = (12 if "rgb" in want else 0) + 3
         ms_per_step = elapsed / a.steps * 1e3
         fps = views_all * a.steps / elapsed
         blend_s = max(tile_ms, 1e-9) * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
@@ -340,7 +330,7 @@ def main():
             "passes": [{"value": views_all * a.steps / t, "ms_per_step": t / a.steps * 1e3} for t in pass_times],
             "cold_start": {"value": views_all * a.steps / cold_elapsed, "unit": "frames/s", "ms_per_step": cold_elapsed / a.steps * 1e3,
                            "what": "the same W warm-up + K timed steps started on the idle GPU (first ~25 ms: clock ramp)"},
-            "config": {"workload": desc, "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"], "n_intersections_binned": binned,
+            "config": {"workload": desc, "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
                        "views_per_step": views_all, "parallelism": f"views{world}x{V}",
                        "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -115,7 +115,6 @@ struct sas_ctx {
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
     // cameras) in groups that share one set of launches (grid.y = view).  SAS_GROUP=1 disables, 2..4 sets the size.
     int group_views = -1;           // -1: half of the slots (two groups can be in flight)
-    bool tight_tiles = false;       // SAS_TIGHT=1: bin only the tiles of gsplat's rectangle the footprint reaches (measured: no gain)
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
@@ -273,8 +272,6 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
     f.n_wg = (int)std::max<int64_t>(1, (c->scene.n + 255) / 256);
     f.n_tiles = tiles;
-    // tight tiles unless the frame keeps gsplat's rectangle lists for the parity hooks (SAS_FULL_SORT) or SAS_TIGHT=0
-    f.tight = (c->tight_tiles && !(sl.args.flags & SAS_FULL_SORT)) ? 1 : 0;
     return f;
 }
 
@@ -622,7 +619,6 @@ int sas_create(int device, sas_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
     }
-    if (const char *e = getenv("SAS_TIGHT")) c->tight_tiles = atoi(e) != 0;
     if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SAS_QUAD_TILES")) {
         const int v = atoi(e);

@@ -73,43 +73,6 @@ DEV float c_logf(float x)
     return fma_((float)e, 0.6931471805599453f, lnm);
 }
 
-// ---- tight tiles (contract, mirrors oracle/sas_oracle.c tile_reached) -----------------------------------------------
-// gsplat bins a Gaussian into every tile of the bounding RECTANGLE of its footprint; an elongated or diagonal footprint
-// misses many of them (17 % of the entries staged at config 3 reach no pixel of their tile).  A splat composites at a
-// pixel only where alpha >= 1/255, i.e. sigma <= ln(255 o) = thr - 1e-3, so a tile whose pixel centres all have
-// sigma > thr + 0.05 is skipped at binning time: same image, shorter lists.  The test is EXACT up to that margin: the
-// minimum of the convex quadratic over the rectangle spanned by the tile's pixel centres lies, when the mean is outside
-// it, on an edge that faces the mean (at most two), at the clamped stationary point of that edge.  The 0.05 is three
-// orders of magnitude above the rounding difference between this evaluation and the per-pixel polynomial.
-// nba = -B / A, nbc = -B / C (two divisions per Gaussian, outside the tile loop).
-struct TileReach {
-    float mx, my, A, B, C, lim, nba, nbc;
-};
-DEV TileReach tile_reach_of(float mx, float my, float A, float B, float C, float thr)
-{
-    return TileReach{mx, my, A, B, C, thr + 0.05f, -B / A, -B / C};
-}
-DEV bool tile_reached(const TileReach &g, int tx, int ty)
-{
-    const float x0 = (float)(tx * SAS_TILE) + 0.5f, y0 = (float)(ty * SAS_TILE) + 0.5f;
-    const float dx0 = x0 - g.mx, dx1 = (x0 + 15.0f) - g.mx, dy0 = y0 - g.my, dy1 = (y0 + 15.0f) - g.my;
-    const bool in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;
-    if (in_x && in_y) return true;
-    const float hA = 0.5f * g.A, hC = 0.5f * g.C;
-    float best = __builtin_inff();
-    if (!in_x) {   // the vertical edge facing the mean
-        const float dx = dx0 > 0.0f ? dx0 : dx1;
-        const float dy = fminf(fmaxf(g.nbc * dx, dy0), dy1);
-        best = fma_(g.B * dx, dy, fma_(hC * dy, dy, (hA * dx) * dx));
-    }
-    if (!in_y) {   // the horizontal edge facing the mean
-        const float dy = dy0 > 0.0f ? dy0 : dy1;
-        const float dx = fminf(fmaxf(g.nba * dy, dx0), dx1);
-        best = fminf(best, fma_(g.B * dx, dy, fma_(hA * dx, dx, (hC * dy) * dy)));
-    }
-    return !(best > g.lim);
-}
-
 DEV float affine3(float r0, float r1, float r2, float t, float v0, float v1, float v2)
 {
     return fma_(r0, v0, fma_(r1, v1, fma_(r2, v2, t)));

@@ -76,7 +76,6 @@ struct SasFrame {
     const float *group_Rt;     // [n_groups,12] poses of the splat groups for THIS view, or nullptr
     int n_wg;
     int n_tiles;               // tw * th
-    int tight;                 // 1: bin a Gaussian only into the tiles of its rectangle its footprint can reach (tile_reached)
 };
 
 struct SasOutputs {

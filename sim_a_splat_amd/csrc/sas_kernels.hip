@@ -112,15 +112,16 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 constexpr int kSmallRect = 8;
 
 template <typename F>
-DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, bool tight, const TileReach &tr, F emit)
+DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, F emit)
 {
     const int lane = threadIdx.x & 63;
     const int w = x1 - x0;
     const int area = active ? w * (y1 - y0) : 0;
     if (area > 0 && area <= kSmallRect) {
+#pragma unroll 1
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx)
-                if (!tight || tile_reached(tr, tx, ty)) emit(ty * tw + tx, v0, v1);
+#pragma unroll 1
+            for (int tx = x0; tx < x1; ++tx) emit(ty * tw + tx, v0, v1);
     }
     unsigned long long big = __ballot(area > kSmallRect);
     while (big) {
@@ -129,14 +130,8 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
         const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
         const int bw = __shfl(w, src), ba = __shfl(area, src);
         const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
-        TileReach br;
-        br.mx = __shfl(tr.mx, src); br.my = __shfl(tr.my, src);
-        br.A = __shfl(tr.A, src); br.B = __shfl(tr.B, src); br.C = __shfl(tr.C, src);
-        br.lim = __shfl(tr.lim, src); br.nba = __shfl(tr.nba, src); br.nbc = __shfl(tr.nbc, src);
-        for (int i = lane; i < ba; i += 64) {
-            const int tx = bx0 + i % bw, ty = by0 + i / bw;
-            if (!tight || tile_reached(br, tx, ty)) emit(ty * tw + tx, b0, b1);
-        }
+#pragma unroll 1
+        for (int i = lane; i < ba; i += 64) emit((by0 + i / bw) * tw + bx0 + i % bw, b0, b1);
     }
 }
 
@@ -269,15 +264,12 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
-    const bool tight = f.tight != 0;
-    const TileReach tr = vis ? tile_reach_of(g.mx, g.my, g.ca, g.cb, g.ccn, g.thr) : TileReach{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
         __syncthreads();
         if (in_win)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
-                    if (tight && !tile_reached(tr, tx, ty)) continue;
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
                 }
@@ -285,15 +277,24 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
         // one RETURNING atomic per touched tile: the workgroup's run inside the tile's segment is reserved here, and
         // k_scatter (same workgroup, same window) reads where it starts instead of reserving it itself
         int *wb = f.wg_base + (size_t)blockIdx.x * SAS_WIN_BINS;
-        for (int b = threadIdx.x; b < w.area; b += 256) {
-            const int cnt = s_hist[b];
-            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
-            wb[b] = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
+        {   // bin b = row * ww + col of the window, walked in steps of 256 bins without a division per step
+            const unsigned ww = (unsigned)w.ww, tid = threadIdx.x;
+            unsigned row = tid / ww, col = tid - row * ww;
+            const unsigned drow = 256u / ww, dcol = 256u - drow * ww;
+#pragma clang loop unroll(disable)
+            for (unsigned b = tid; b < (unsigned)w.area; b += 256u) {
+                const int cnt = s_hist[b];
+                const int tile = (w.Y0 + (int)row) * tw + w.X0 + (int)col;
+                wb[b] = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
+                row += drow;
+                col += dcol;
+                if (col >= ww) { col -= ww; ++row; }
+            }
         }
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u, tight, tr,
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
                   [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
@@ -697,6 +698,7 @@ DEV void order_body(const SasFrame &f, int wg)
     __syncthreads();
     if (tid < 16) {   // the class's 32 copies become starts inside the workgroup's run of that class
         int sum = 0;
+#pragma unroll 4
         for (int k = 0; k < 32; ++k) { const int v = s_cls[32 * tid + k]; s_cls[32 * tid + k] = sum; sum += v; }
         s_cbase[tid] = sum ? atomicAdd(&f.class_cursor[tid], sum) : 0;
     }
@@ -727,43 +729,54 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
-    // the same reach test on the same floats as the projection's count (its record), hence the same tiles
-    const bool tight = f.tight != 0;
-    TileReach tr{0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-    if (tight && vis) {
-        const float4 r0 = f.rec[3 * i + 0], r1 = f.rec[3 * i + 1];
-        tr = tile_reach_of(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z);
-    }
     if (w.fits) {
         const int *wb = f.wg_base + (size_t)wg * SAS_WIN_BINS;
-        for (int b = threadIdx.x; b < w.area; b += 256) {
-            const int tile = (w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww;
-            s_base[b] = SAS_IN(tile, f.n_tiles, 112) ? f.tile_offset[tile] + wb[b] : 0;
-            s_hist[b] = 0;
+        {   // bin b = row * ww + col of the window, walked in steps of 256 bins without a division per step
+            const unsigned ww = (unsigned)w.ww, tid = threadIdx.x;
+            unsigned row = tid / ww, col = tid - row * ww;
+            const unsigned drow = 256u / ww, dcol = 256u - drow * ww;
+#pragma clang loop unroll(disable)
+            for (unsigned b = tid; b < (unsigned)w.area; b += 256u) {
+                const int tile = (w.Y0 + (int)row) * tw + w.X0 + (int)col;
+                s_base[b] = SAS_IN(tile, f.n_tiles, 112) ? f.tile_offset[tile] + wb[b] : 0;
+                s_hist[b] = 0;
+                row += drow;
+                col += dcol;
+                if (col >= ww) { col -= ww; ++row; }
+            }
         }
         __syncthreads();
         if (in_win)
+#pragma unroll 1
             for (int ty = y0; ty < y1; ++ty)
+#pragma unroll 1
                 for (int tx = x0; tx < x1; ++tx) {
-                    if (tight && !tile_reached(tr, tx, ty)) continue;
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (!SAS_IN(b, kHistBins, 113)) continue;
                     const long long pos = (long long)s_base[b] + atomicAdd(&s_hist[b], 1);
                     // pos >= cap is the documented overflow path (the frame is rendered again); a position
                     // beyond the tile's own segment would be a bug
-                    if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[(w.Y0 + b / w.ww) * tw + w.X0 + b % w.ww + 1], 114)) f.keys[pos] = key;
+                    if (pos < f.cap && SAS_IN(pos, (long long)f.tile_offset[ty * tw + tx + 1], 114)) f.keys[pos] = key;
                 }
     }
     const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, tight, tr, [&](int tile, unsigned lo, unsigned hi) {
+    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, klo, khi, [&](int tile, unsigned lo, unsigned hi) {
         if (!SAS_IN(tile, f.n_tiles, 115)) return;
         const int pos = atomicAdd(&f.tile_cursor[tile], 1);
         if ((long long)pos < f.cap && SAS_IN(pos, f.tile_offset[tile + 1], 116)) f.keys[pos] = ((unsigned long long)hi << 32) | lo;
     });
 }
 
-__global__ __launch_bounds__(256) void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body(s, tw, f); }
-__global__ __launch_bounds__(256) void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
+// 32 VGPRs: in steady state the register file is what the frames in flight compete for (five tile-kernel waves of 96
+// VGPRs leave 32 per SIMD lane): a scatter wave that fits into the remainder runs BESIDE a full complement of tile waves
+// instead of displacing one (wave slots 5 + 1 of 8, LDS 5 x 27 + 18.5 of 160 KB).  Left to itself the compiler takes 46:
+// the kernel's LDS caps it at eight waves per SIMD, below which registers look free.
+#ifndef SAS_TUNE_SCATTER_VGPR
+#define SAS_TUNE_SCATTER_VGPR 32
+#endif
+#define SAS_SCATTER_ATTRS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SAS_TUNE_SCATTER_VGPR)))
+__global__ SAS_SCATTER_ATTRS void k_scatter(SasScene s, int tw, SasFrame f) { scatter_body(s, tw, f); }
+__global__ SAS_SCATTER_ATTRS void k_scatter_multi(SasScene s, int tw, SasMulti mf) { scatter_body(s, tw, mf.f[blockIdx.y]); }
 
 }  // namespace
 

@@ -134,9 +134,3 @@ def real_link_masks(scene):
         masks = {str(k): np.unpackbits(b, count=n).astype(bool) for k, b in zip(z["link_names"], z["mask_bits"])}
         return masks, z["icp_transformation"].copy(), n
 
-
-def binned(ref, full_sort=False):
-    """Intersections a frame bins, from the oracle's counts: gsplat's bounding rectangles -- or, with SAS_TIGHT=1 (an
-    option: measured without gain, off by default) and not SAS_FULL_SORT, only the tiles of them the footprint reaches."""
-    import os
-    return ref["n_isect_tight"] if (os.environ.get("SAS_TIGHT") == "1" and not full_sort) else ref["n_isect"]

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import TWIN_CASES, binned, load_twin_fixture, twin_scene_kwargs
+from conftest import TWIN_CASES, load_twin_fixture, twin_scene_kwargs
 from sim_a_splat_amd.synthetic import (NERFSTUDIO_EVAL_BACKGROUND, config_scene_and_cameras, make_scene,
                                        random_group_poses, ring_camera)
 
@@ -31,7 +31,7 @@ def _compare(r, sc, cam, group_id=None, group_Rt=None, exact=True, depth_fill=Fa
     got = {k: v.cpu().numpy() for k, v in out.items()}
     st = r.stats()
     assert st["n_visible"] == ref["n_visible"]
-    assert st["n_isect"] == binned(ref, full_sort)
+    assert st["n_isect"] == ref["n_isect"]
     assert np.abs(got["rgb"] - ref["rgb"]).max() <= TOL
     assert np.abs(got["alpha"] - ref["alpha"]).max() <= TOL
     m = ref["alpha"] > 0.5
@@ -333,7 +333,7 @@ def test_golden_twin_fixtures_through_the_c_abi(rasterizer, name):
     st = rasterizer.stats()
     ref = oracle.render(means, op, colors, g["viewmat"], g["K"], W, H, group_Rt=g["group_Rt"] if gid is not None else None,
                         background=bg, **kw)
-    assert ref["n_isect"] == int(g["n_isect"]) and st["n_isect"] == binned(ref) and ref["n_isect_tight"] <= ref["n_isect"]
+    assert ref["n_isect"] == int(g["n_isect"]) == st["n_isect"]
     assert st["n_visible"] == int(g["valid"].sum())
     rasterizer.render(g["viewmat"], g["K"], W, H, bg, want=("rgb",), full_sort=True)
     assert rasterizer.stats()["n_isect"] == int(g["n_isect"])
@@ -468,7 +468,7 @@ def test_launch_groups_equal_single_views(monkeypatch, group):
     _upload(r, big)
     bc = [ring_camera(640, 480, 500.0, yaw_deg=90.0 * k) for k in range(2)]
     refs = [oracle.render_scene(big, c_, background=BG) for c_ in bc]
-    assert min(binned(ref) for ref in refs) > (1 << 20)
+    assert min(ref["n_isect"] for ref in refs) > (1 << 20)
     out = r.render_batch(np.stack([c_.viewmat for c_ in bc]), np.stack([c_.K for c_ in bc]), 640, 480, BG, want=("rgb",))
     assert r.stats()["regrows"] >= 1
     for v in range(2):
@@ -506,10 +506,10 @@ def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch):
     _upload(r, sc)
     cams = [ring_camera(640, 480, 500.0, yaw_deg=0.0), ring_camera(640, 480, 500.0, yaw_deg=90.0)]
     refs = [oracle.render_scene(sc, c, background=BG) for c in cams]
-    assert min(binned(ref) for ref in refs) > (1 << 20)
+    assert min(ref["n_isect"] for ref in refs) > (1 << 20)
     got = r.render(cams[0].viewmat, cams[0].K, 640, 480, BG, want=("rgb",))["rgb"].cpu().numpy()
     st = r.stats()
-    assert st["regrows"] >= 1 and st["capacity"] >= st["n_isect"] == binned(refs[0])
+    assert st["regrows"] >= 1 and st["capacity"] >= st["n_isect"] == refs[0]["n_isect"]
     assert np.array_equal(got, refs[0]["rgb"])
     r.close()
     r = Rasterizer("cuda:0")                     # fresh buffers: now the pair overflows, both slots
@@ -535,7 +535,7 @@ def test_stream_ordered_consumer_of_overflowing_async_frames():
     _upload(r, sc)
     cams = [ring_camera(640, 480, 500.0, yaw_deg=90.0 * (k % 2)) for k in range(7)]
     refs = [oracle.render_scene(sc, c, background=BG) for c in cams[:2]]
-    assert min(binned(ref) for ref in refs) > (1 << 20)
+    assert min(ref["n_isect"] for ref in refs) > (1 << 20)
     outs = [torch.empty((480, 640, 3), device="cuda:0") for _ in cams]
     copies, taken = [], 0
     for k, c in enumerate(cams):
@@ -775,7 +775,7 @@ def test_randomised_edge_cases(rasterizer, seed):
                             sh_degree=deg, background=BG, want_rgb8=True, depth_mode=1)
     out = rasterizer.render(cam.viewmat, K, W, H, BG, want=("rgb", "alpha", "depth", "rgb8"), depth_fill_max=True)
     st = rasterizer.stats()
-    assert st["n_visible"] == ref["n_visible"] and st["n_isect"] == binned(ref)
+    assert st["n_visible"] == ref["n_visible"] and st["n_isect"] == ref["n_isect"]
     for k in ("rgb", "alpha", "depth", "rgb8"):
         got = out[k].cpu().numpy()
         assert np.abs(got.astype(np.float64) - ref[k]).max() <= (1 if k == "rgb8" else 1e-4), k
@@ -871,27 +871,3 @@ def test_per_view_pose_sets_of_vectorised_envs(rasterizer):
     with pytest.raises(Exception):
         rasterizer.render_batch(Vs, Ks, 160, 120, BG, pose_sets=sets, pose_set=[9] * (2 * E))
 
-
-def test_tight_tiles_option(monkeypatch):
-    """SAS_TIGHT=1: a Gaussian is binned only into the tiles of gsplat's rectangle its footprint can reach (exact
-    minimum of sigma over the tile's pixel-centre rectangle, margin 0.05).  Same image bit for bit, fewer
-    intersections -- exactly the oracle's tight count -- on elongated splats, a launch group and a view pair."""
-    import torch
-    from sim_a_splat_amd.rasterizer import Rasterizer
-    monkeypatch.setenv("SAS_TIGHT", "1")
-    monkeypatch.setenv("SAS_PAIR", "1")
-    r = Rasterizer("cuda:0")
-    try:
-        sc = make_scene(30000, seed=909, log_scale_mean=float(np.log(0.03)))
-        sc.scales[:, 0] *= 6.0                                   # elongated: bounding rectangles far larger than the footprints
-        _upload(r, sc)
-        cam = ring_camera(320, 240, 280.0, yaw_deg=15.0, elev=0.3)
-        got, ref = _compare(r, sc, cam, depth_fill=True)
-        assert r.stats()["n_isect"] == ref["n_isect_tight"] < 0.8 * ref["n_isect"]
-        cams = [ring_camera(320, 240, 280.0, yaw_deg=y) for y in (0.0, 120.0)]
-        batch = r.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 320, 240, BG, want=("rgb",))
-        for v, c in enumerate(cams):
-            assert np.array_equal(batch["rgb"][v].cpu().numpy(), oracle.render_scene(sc, c, background=BG)["rgb"]), v
-        _compare(r, sc, cam, full_sort=True)                     # gsplat's rectangles for the list read-back
-    finally:
-        r.close()
