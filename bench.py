@@ -303,6 +303,7 @@ def main():
             r.render(c_.viewmat, c_.K, W, H, BG, want=("rgb8",), out={"rgb8": bufs[0]["rgb8"][0]})
             per_view.append(r.stats())
         st = {k: int(round(np.mean([pv[k] for pv in per_view]))) for k in ("n_visible", "n_isect")}
+        out_bpp = (12 if "rgb" in want else 0) + 3
         ms_per_step = elapsed / a.steps * 1e3
         fps = views_all * a.steps / elapsed
         blend_s = max(tile_ms, 1e-9) * 1e-3   # mean duration of k_tile_lazy over the timed region (HIP events on its stream)
