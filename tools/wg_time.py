@@ -34,4 +34,12 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     for q in (0.25, 0.5, 0.75, 0.9):
         print(f"  {int(q * 100)} % of the workgroups have ended by {np.quantile(e, q):6.1f} us", end=";")
     print()
+    # slot time by list-length class: where the workgroup-microseconds go
+    edges = [0, 1, 65, 257, 513, 1025, 2049, 4097, 1 << 30]
+    names = ["empty", "1-64", "65-256", "257-512", "513-1024", "1025-2048", "2049-4096", "> 4096"]
+    for lo, hi, nm in zip(edges[:-1], edges[1:], names):
+        m = (ln >= lo) & (ln < hi)
+        if m.any():
+            print(f"  lists {nm:10s}: {int(m.sum()):5d} workgroups, mean {d[m].mean():6.1f} us, {100 * d[m].sum() / d.sum():5.1f} % of the slot time, "
+                  f"{d[m].sum() / max(ln[m].sum(), 1) * 1e3:7.1f} ns per key")
     r.close()
