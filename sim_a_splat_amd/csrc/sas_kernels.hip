@@ -10,8 +10,8 @@
 //               T5      its LAST workgroup to finish (ticket) scans the counts: tile_offset, scatter
 //                       cursors, tiles ordered by list-length class, statistics straight to pinned host
 //                       memory -- no scan kernel, no memset, no read-back copy around a frame
-//   k_scatter   T3      (depth bits | storage slot) keys into per-tile segments, runs reserved per
-//                       (workgroup, tile) with one returning atomic
+//   k_scatter   T3      (depth bits | storage slot) keys into per-tile segments, into the runs the projection
+//                       reserved per (workgroup, tile); its front workgroups put the tiles in launch order
 //
 // ARITHMETIC CONTRACT: every value that reaches an output is produced by the same
 // sequence of IEEE binary32 operations as oracle/sas_oracle.c -- explicit __builtin_fmaf where
@@ -297,7 +297,7 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
     for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
                   [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
-    // serialise at ~90 atomics/us); k_scan adds the per-workgroup counts up
+    // serialise at ~90 atomics/us); the projection's tail adds the per-workgroup counts up
     if (threadIdx.x == 0) *s_nvis = 0;
     __syncthreads();
     const unsigned long long vb = __ballot(vis);

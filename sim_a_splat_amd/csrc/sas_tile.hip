@@ -257,7 +257,7 @@ __device__ __attribute__((noinline)) void sort_ids_bitonic(const unsigned long l
 // Full path, stage 1: k_sort_* write every tile's complete front-to-back list (storage slots)
 // ================================================================================================
 // Tiles come from a list (`tl[range[0] .. range[1])`): the three size classes are contiguous
-// ranges of the length-ordered tile list built by k_scan, and the lazy kernel's fallback tiles are
+// ranges of the length-ordered tile list (tile_order: k_scatter's front workgroups), and the lazy kernel's fallback tiles are
 // a list of their own.  Workgroups stride over the range.
 
 template <int CAP, int THREADS, bool LAST_CLASS>

@@ -1,5 +1,6 @@
-"""Kernel timeline of blocking steps from a rocprofv3 --kernel-trace CSV: per step (prologue kernel ... epilogue
-kernel) the kernel durations and the idle gaps between them.  python tools/step_gaps.py t_kernel_trace.csv"""
+"""Kernel timeline of blocking steps from a rocprofv3 --kernel-trace CSV: per step (a step starts with its pose upload
+or, for scenes without splat groups, its projection, and ends with its last kernel) the kernel durations and the idle
+gaps between them.  python tools/step_gaps.py t_kernel_trace.csv"""
 import csv, re, sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
@@ -8,10 +9,11 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 steps, cur = [], []
 for s, e, n in rows:
-    if n.startswith("k_frame_prologue") and cur:
+    first = n.startswith("k_pose_upload") or (n.startswith("k_project") and not any(m.startswith("k_pose_upload") for _, _, m in cur))
+    if first and cur:
         steps.append(cur); cur = []
     cur.append((s, e, n))
-steps = [st for st in steps if any(n.startswith("k_frame_epilogue") for _, _, n in st)][20:-5]
+steps = [st for st in steps if any(n.startswith("k_tile_lazy") for _, _, n in st)][20:-5]
 import collections
 dur, gap, span, between = collections.defaultdict(list), collections.defaultdict(list), [], []
 prev_end = None
