@@ -270,6 +270,7 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.wg_vis = (int *)q.wgvis.p;
     f.tile_max = (unsigned *)q.tilemax.p;
     f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
+    f.group_host = c->scene.n_groups > 0 ? sl.poses_host : nullptr;
     f.n_wg = (int)std::max<int64_t>(1, (c->scene.n + 255) / 256);
     f.n_tiles = tiles;
     return f;
@@ -302,9 +303,10 @@ bool kernel_can_write_host(sas_ctx *c, const void *p)
 
 // Group poses of the n frames (one launch): each slot's snapshot goes to its own device block, so frames in flight
 // may carry different poses (vectorised envs, a pose update per Gym step) and nothing drains between them.
-int enqueue_poses(sas_ctx *c, Slot *const *sl, int n, hipStream_t st)
+int enqueue_poses(sas_ctx *c, Slot *const *sl, int n, hipStream_t st, bool multi)
 {
     if (c->scene.n_groups <= 0) return SAS_OK;
+    if (sas_poses_inline(c->scene.n_groups, n, multi)) return SAS_OK;   // small blocks ride in the projection's arguments
     SasPoseUpload u{};
     u.nv = n;
     for (int k = 0; k < n; ++k) {
@@ -386,7 +388,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     if (timing) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (role != ROLE_FOLLOWER) {
         Slot *mem[1] = {&sl};
-        if ((rc = enqueue_poses(c, mem, 1, st))) return rc;   // a pair shares its poses: the leader's block serves both views
+        if ((rc = enqueue_poses(c, mem, 1, st, false))) return rc;   // a pair shares its poses: the leader's block serves both views
     }
     if (role == ROLE_FOLLOWER) HIP_TRY(c, hipStreamWaitEvent(st, partner->pair_ev, 0));
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[0], st));
@@ -456,7 +458,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         mf.f[k] = frame_of(c, *sl[k], tiles);
         mf.P[k] = sl[k]->params;
     }
-    if ((rc = enqueue_poses(c, sl, n, st))) return rc;
+    if ((rc = enqueue_poses(c, sl, n, st, true))) return rc;
     HIP_TRY(c, hipEventRecord(ld.start, a.stream));
     sas_launch_project_multi(st, c->scene, mf);
     sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);

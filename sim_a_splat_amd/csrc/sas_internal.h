@@ -73,7 +73,9 @@ struct SasFrame {
     unsigned *stats_host;      // [8] pinned
     int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup
     unsigned *tile_max;        // [4 * tiles] per-tile (quad layout: per-quadrant) max expected depth (bits), written when depth is filled
-    const float *group_Rt;     // [n_groups,12] poses of the splat groups for THIS view, or nullptr
+    const float *group_Rt;     // [n_groups,12] poses of the splat groups for THIS view (device), or nullptr
+    const float *group_host;   // the same rows on the host (the slot's pinned snapshot): small pose blocks ride in the
+                               // projection's argument segment instead of being uploaded (sas_poses_inline)
     int n_wg;
     int n_tiles;               // tw * th
 };
@@ -99,11 +101,21 @@ struct SasParams {
 
 // Up to SAS_MAX_GROUP same-sized views rendered by ONE set of launches: the cameras of a Gym step.  Passed to the
 // *_multi kernels by value.
+#define SAS_MULTI_INLINE_ROWS 32   // pose rows (all views together) a launch group carries in its argument segment
+#define SAS_PROJ_INLINE_ROWS 16    // ... a single view / a view pair
 struct SasMulti {
     SasFrame f[SAS_MAX_GROUP];
     SasParams P[SAS_MAX_GROUP];
     int nv;
+    int pose_inline;                            // 1: view k's poses are pose_rows + pose_off[k] (set by the launcher)
+    int pose_off[SAS_MAX_GROUP];
+    float pose_rows[12 * SAS_MULTI_INLINE_ROWS];
 };
+// Will the projection launch carry the poses itself (no upload kernel, no dependent-kernel gap in front of it)?
+static inline bool sas_poses_inline(int n_groups, int n_views, bool multi)
+{
+    return n_groups > 0 && (multi ? n_groups * n_views <= SAS_MULTI_INLINE_ROWS : n_groups <= SAS_PROJ_INLINE_ROWS);
+}
 
 // Group poses of the views of a launch: ONE small kernel copies each view's [rows, 12] block into that view's device
 // buffer -- from its own argument segment when the rows of all views fit (SAS_POSE_INLINE_ROWS), else from PINNED

@@ -19,6 +19,8 @@
 // (hipcc default), polynomial exp/log.  No MFMA: nothing here is a dense contraction.
 #include "sas_device.h"
 
+#include <cstring>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -190,6 +192,8 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
 struct ProjArgs {
     SasCam cam[2];
     SasFrame f[2];
+    int pose_inline;                             // 1: the group poses are pose_rows (small blocks: no upload kernel)
+    float pose_rows[12 * SAS_PROJ_INLINE_ROWS];
 };
 
 // camera-dependent results of one Gaussian for one view
@@ -448,8 +452,13 @@ DEV float4 scene_load(const float4 *p)
     else return *p;
 }
 
-template <int DEG, int NV>
-DEV void project_body(const SasScene &s, const ProjArgs &vs)
+// Group poses reach a lane in one of two ways: from the slot's device block (12 per-lane loads), or -- small pose
+// blocks, `inline_row(g, k)` -- from the launch's ARGUMENT segment: the scene is stored by group, so a wave almost
+// always holds one group; its row is fetched with scalar loads at a uniform index (no upload kernel in front of the
+// projection, no address of the argument struct taken: that would make the compiler copy it to scratch).
+template <int DEG, int NV, typename RowFn>
+DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses /* [n_groups,12] device, or nullptr */,
+                      bool poses_inline, RowFn inline_row)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < s.n;
@@ -464,9 +473,27 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs)
         const float4 a2 = scene_load<NV>(s.g2 + i);
         float m[3] = {a0.x, a0.y, a0.z};
         const float op = a0.w;
-        const float *G = nullptr;
-        if (vs.f[0].group_Rt) {   // the views of one pass share their group poses
-            G = vs.f[0].group_Rt + 12 * (__float_as_uint(a2.w) & 255u);
+        const bool hasG = poses_inline || poses != nullptr;   // the views of one pass share their group poses
+        float G[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+        const unsigned gid = __float_as_uint(a2.w) & 255u;
+        if (poses_inline) {
+            unsigned long long todo = __ballot(true);
+            while (todo) {
+                const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)todo) - 1);
+                const bool mine = gid == g;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const float r = inline_row(g, k);   // uniform: scalar load
+                    if (mine) G[k] = r;
+                }
+                todo &= ~__ballot(mine);
+            }
+        } else if (poses) {
+            const float *Gp = poses + 12 * gid;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) G[k] = Gp[k];
+        }
+        if (hasG) {
             float mg0 = affine3(G[0], G[1], G[2], G[3], m[0], m[1], m[2]);
             float mg1 = affine3(G[4], G[5], G[6], G[7], m[0], m[1], m[2]);
             float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
@@ -499,7 +526,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs)
                 R[0] = fma_(-2.0f, y2 + z2, 1.0f); R[1] = 2.0f * (xy - wz);           R[2] = 2.0f * (xz + wy);
                 R[3] = 2.0f * (xy + wz);           R[4] = fma_(-2.0f, x2 + z2, 1.0f); R[5] = 2.0f * (yz - wx);
                 R[6] = 2.0f * (xz - wy);           R[7] = 2.0f * (yz + wx);           R[8] = fma_(-2.0f, x2 + y2, 1.0f);
-                if (G) {
+                if (hasG) {
                     float R2[9];
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
@@ -523,7 +550,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs)
                 cov[5] = dot3(M[6], M[7], M[8], M[6], M[7], M[8]);
             } else {
                 cov[0] = a1.x; cov[1] = a1.y; cov[2] = a1.z; cov[3] = a1.w; cov[4] = a2.x; cov[5] = a2.y;
-                if (G) {
+                if (hasG) {
                     const float Rg[9] = {G[0], G[1], G[2], G[4], G[5], G[6], G[8], G[9], G[10]};
                     float c2[6];
                     rot_sym3(Rg, cov, c2);
@@ -616,7 +643,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs)
 template <int DEG, int NV>
 __global__ __launch_bounds__(256) void k_project(SasScene s, ProjArgs vs)
 {
-    project_body<DEG, NV>(s, vs);
+    project_body<DEG, NV>(s, vs, vs.f[0].group_Rt, vs.pose_inline != 0, [&](unsigned g, int k) { return vs.pose_rows[12u * g + (unsigned)k]; });
 }
 
 // all views of a group in one launch: blockIdx.y = view, one pass over the (small) scene per view
@@ -626,7 +653,8 @@ __global__ __launch_bounds__(256) void k_project_multi(SasScene s, SasMulti mf)
     ProjArgs vs;
     vs.cam[0] = vs.cam[1] = mf.P[blockIdx.y].cam;
     vs.f[0] = vs.f[1] = mf.f[blockIdx.y];
-    project_body<DEG, 1>(s, vs);
+    const unsigned off = (unsigned)mf.pose_off[blockIdx.y];
+    project_body<DEG, 1>(s, vs, mf.f[blockIdx.y].group_Rt, mf.pose_inline != 0, [&](unsigned g, int k) { return mf.pose_rows[off + 12u * g + (unsigned)k]; });
 }
 
 // ---- small kernels around a frame ---------------------------------------------------------------------
@@ -807,11 +835,18 @@ static void launch_project(hipStream_t st, const SasScene &s, const ProjArgs &vs
     }
 }
 
+static void inline_poses(ProjArgs &vs, const SasScene &s)
+{
+    vs.pose_inline = sas_poses_inline(s.n_groups, 1, false) && vs.f[0].group_host ? 1 : 0;
+    if (vs.pose_inline) memcpy(vs.pose_rows, vs.f[0].group_host, sizeof(float) * 12 * (size_t)s.n_groups);
+}
+
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams &P, const SasFrame &f)
 {
     ProjArgs vs;
     vs.cam[0] = vs.cam[1] = P.cam;
     vs.f[0] = vs.f[1] = f;
+    inline_poses(vs, s);
     launch_project<1>(st, s, vs);
 }
 
@@ -821,11 +856,20 @@ void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams &P0,
     ProjArgs vs;
     vs.cam[0] = P0.cam; vs.cam[1] = P1.cam;
     vs.f[0] = f0; vs.f[1] = f1;
+    inline_poses(vs, s);
     launch_project<2>(st, s, vs);
 }
 
-void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti &mf)
+void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti &mf_in)
 {
+    static_assert(sizeof(SasMulti) <= 4096, "kernel argument segment");
+    SasMulti mf = mf_in;
+    mf.pose_inline = sas_poses_inline(s.n_groups, mf.nv, true) ? 1 : 0;
+    for (int k = 0; k < mf.nv && mf.pose_inline; ++k) {
+        if (!mf.f[k].group_host) { mf.pose_inline = 0; break; }
+        mf.pose_off[k] = 12 * s.n_groups * k;
+        memcpy(mf.pose_rows + mf.pose_off[k], mf.f[k].group_host, sizeof(float) * 12 * (size_t)s.n_groups);
+    }
     const dim3 grid((unsigned)mf.f[0].n_wg, (unsigned)mf.nv);
     switch (s.sh_degree) {
         case 0: hipLaunchKernelGGL((k_project_multi<0>), grid, dim3(256), 0, st, s, mf); break;
