@@ -73,6 +73,7 @@ struct Slot {
     SasParams params{};
     bool busy = false, timed = false, timed_tiles = false;
     bool quad = false;   // the frame's tile kernel was launched in its quad layout
+    bool host_direct = false;   // the tile kernel delivers the uint8 frame to pinned host memory itself
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
 };
 
@@ -358,6 +359,12 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     SasParams &hp = sl.params;
     hp.cam = cam;
     hp.out.rgb = a.rgb; hp.out.alpha = a.alpha; hp.out.depth = a.depth; hp.out.rgb8 = a.rgb8;
+    // frame wanted in pinned host memory and every tile complete: the tile kernel stores its rows there itself
+    // (no device staging frame, no copy kernel); SAS_FULL_SORT frames keep the staging path
+    sl.host_direct = a.rgb8_host && a.W % SAS_TILE == 0 && a.H % SAS_TILE == 0 && ((size_t)a.rgb8_host & 15) == 0 &&
+                     !(a.flags & SAS_FULL_SORT) && kernel_can_write_host(c, a.rgb8_host);
+    hp.out.rgb8_host = sl.host_direct ? a.rgb8_host : nullptr;
+    if (sl.host_direct) hp.out.rgb8 = nullptr;
     hp.out.bg[0] = a.bg[0]; hp.out.bg[1] = a.bg[1]; hp.out.bg[2] = a.bg[2];
     hp.out.points = a.points; hp.out.mask = a.mask;
     hp.out.max_depth = a.max_depth; hp.out.use_max_depth = a.use_max_depth ? 1 : 0;
@@ -418,7 +425,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     const bool pts = a.depth && (a.points || a.mask);
     if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
-    if (a.rgb8_host && a.rgb8) {   // frame wanted on the host: by a kernel when the destination is pinned (no copy-engine hop)
+    if (a.rgb8_host && a.rgb8 && !sl.host_direct) {   // frame wanted on the host and not delivered by the tile kernel: by a copy kernel when the destination is pinned (no copy-engine hop)
         const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
         if (kernel_can_write_host(c, a.rgb8_host)) {
             SasHostCopy h{};
@@ -479,12 +486,12 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     {   // frames wanted on the host (sas_render_batch_host): by a kernel when the destination is pinned
         const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
         bool any = false;
-        for (int k = 0; k < n; ++k) any = any || (sl[k]->args.rgb8_host && sl[k]->args.rgb8);
+        for (int k = 0; k < n; ++k) any = any || (sl[k]->args.rgb8_host && sl[k]->args.rgb8 && !sl[k]->host_direct);
         if (any && kernel_can_write_host(c, a.rgb8_host ? a.rgb8_host : sl[n - 1]->args.rgb8_host)) {
             SasHostCopy h{};
             h.nv = n;
             for (int k = 0; k < n; ++k) {
-                h.src[k] = sl[k]->args.rgb8_host ? sl[k]->args.rgb8 : nullptr;
+                h.src[k] = (sl[k]->args.rgb8_host && !sl[k]->host_direct) ? sl[k]->args.rgb8 : nullptr;
                 h.dst[k] = sl[k]->args.rgb8_host;
             }
             h.bytes = fb;
@@ -492,7 +499,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         } else if (any) {
             for (int k = 0; k < n; ++k) {
                 const RenderArgs &ak = sl[k]->args;
-                if (ak.rgb8_host && ak.rgb8) HIP_TRY(c, hipMemcpyAsync(ak.rgb8_host, ak.rgb8, fb, hipMemcpyDeviceToHost, st));
+                if (ak.rgb8_host && ak.rgb8 && !sl[k]->host_direct) HIP_TRY(c, hipMemcpyAsync(ak.rgb8_host, ak.rgb8, fb, hipMemcpyDeviceToHost, st));
             }
         }
     }

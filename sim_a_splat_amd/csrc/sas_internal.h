@@ -83,6 +83,10 @@ struct SasFrame {
 struct SasOutputs {
     float *rgb, *alpha, *depth;
     uint8_t *rgb8;
+    // uint8 frame wanted in PINNED HOST memory and every tile complete (W, H multiples of 16): the tile kernel packs its
+    // tile's rows in LDS and stores them to the host itself (16 bytes per lane; 8 in the quad layout), tile by tile while
+    // the kernel runs -- no device staging frame, no copy kernel behind the frame.  nullptr otherwise.
+    uint8_t *rgb8_host;
     float bg[3];
     // RGB-D tail (sas_render_rgbd): camera-frame points [H,W,3] and depth mask [H,W], or nullptr
     float *points;

@@ -998,8 +998,9 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
 }
 
 // T0 epilogue for this thread's pixel; returns its expected depth (0 outside the image).
-DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W)
+DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W, unsigned &rgb8_packed)
 {
+    rgb8_packed = 0u;
     if (!inside) return 0.0f;
     const float a = 1.0f - p.T;
     const float ED = p.d / fmaxf(a, 1e-10f);
@@ -1019,12 +1020,39 @@ DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int i
     }
     if (o.alpha) o.alpha[pix] = a;
     if (o.depth) o.depth[pix] = ED;
-    if (o.rgb8) {
-        o.rgb8[3 * pix] = (uint8_t)(int)floorf(fma_(v0, 255.0f, 0.5f));
-        o.rgb8[3 * pix + 1] = (uint8_t)(int)floorf(fma_(v1, 255.0f, 0.5f));
-        o.rgb8[3 * pix + 2] = (uint8_t)(int)floorf(fma_(v2, 255.0f, 0.5f));
+    if (o.rgb8 || o.rgb8_host) {
+        const unsigned b0 = (unsigned)(int)floorf(fma_(v0, 255.0f, 0.5f)), b1 = (unsigned)(int)floorf(fma_(v1, 255.0f, 0.5f)),
+                       b2 = (unsigned)(int)floorf(fma_(v2, 255.0f, 0.5f));
+        rgb8_packed = b0 | (b1 << 8) | (b2 << 16);
+        if (o.rgb8) {
+            o.rgb8[3 * pix] = (uint8_t)b0;
+            o.rgb8[3 * pix + 1] = (uint8_t)b1;
+            o.rgb8[3 * pix + 2] = (uint8_t)b2;
+        }
     }
     return ED;
+}
+
+// The workgroup's pixels (a 16x16 tile, or an 8x8 quadrant in the quad layout; every pixel inside the image) as packed
+// rows straight to PINNED HOST memory: bytes gathered in LDS, then ROWS x 3 lanes store 16 (8) bytes each.  All threads
+// call it; `lds` is free at this point (the compositing is over).
+template <int SIDE>   // 16: tile, 8: quadrant
+DEV void store_rows_to_host(uint8_t *host, int W, int X0, int Y0, int ox, int oy, bool writer, unsigned rgb8_packed, unsigned char *lds)
+{
+    constexpr int ROWB = 3 * SIDE;          // 48 or 24 bytes per row
+    __syncthreads();                        // the staging buffers of the last batch are no longer read
+    if (writer) {
+        unsigned char *d = lds + oy * ROWB + 3 * ox;
+        d[0] = (unsigned char)rgb8_packed; d[1] = (unsigned char)(rgb8_packed >> 8); d[2] = (unsigned char)(rgb8_packed >> 16);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 3 * SIDE) {
+        const int row = t / 3, seg = t - 3 * row;
+        uint8_t *dst = host + ((long long)(Y0 + row) * W + X0) * 3;
+        if constexpr (SIDE == 16) reinterpret_cast<uint4 *>(dst)[seg] = reinterpret_cast<const uint4 *>(lds + row * ROWB)[seg];
+        else reinterpret_cast<uint2 *>(dst)[seg] = reinterpret_cast<const uint2 *>(lds + row * ROWB)[seg];
+    }
 }
 
 // per-tile max of the expected depth (reduced over tiles by k_depth_tail); all threads call it
@@ -1066,7 +1094,9 @@ __global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long lon
         const int *ids = f.sorted_ids + beg;
         blend_range<FAST_EXP>(f, n_gauss, tx, ty, pix_const(ox, oy), (int)(end - beg),
                               [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
-        const float ED = write_pixel(o, p, inside, ix, iy, c.W);
+        unsigned packed;
+        const float ED = write_pixel(o, p, inside, ix, iy, c.W, packed);
+        if (o.rgb8_host) store_rows_to_host<16>(o.rgb8_host, c.W, tx * SAS_TILE, ty * SAS_TILE, ox, oy, true, packed, s_raw);
         if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
         if (tid == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
     }
@@ -1165,6 +1195,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     PixConst pc = pix_const(ox, oy);
     bool inside = ix < c.W && iy < c.H;
     bool writer = !QUAD || (lane & 3) == 0;   // QUAD: the four lanes of a pixel hold the same state, one stores it
+    int out_side = QUAD ? 8 : 16;             // what this workgroup hands out: its quadrant, the whole tile, or (0) nothing
     PixState p = pix_init(inside, ox);
     bool wdone = __all(!inside);
     // composite `count` ordered entries in this kernel's layout
@@ -1413,6 +1444,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             // the whole segment in place (slow, rare) and composite it from scratch.
             if (QUAD && qd != 0) {
                 writer = false;
+                out_side = 0;
             } else {
                 if (tid == 0) __hip_atomic_fetch_add(&f.stats_host[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 int *out = f.sorted_ids + beg;
@@ -1426,6 +1458,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                     pc = pix_const(ox, oy);
                     inside = ix < c.W && iy < c.H;
                     writer = true;
+                    out_side = 16;
                 }
                 p = pix_init(inside, ox);
                 wdone = __all(!inside);
@@ -1433,7 +1466,13 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             }
         }
     }
-    const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W);
+    unsigned packed;
+    const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W, packed);
+    if (o.rgb8_host) {   // (uniform: a frame property; out_side is uniform over the workgroup)
+        if (out_side == 16) store_rows_to_host<16>(o.rgb8_host, c.W, tx * SAS_TILE, ty * SAS_TILE, ox, oy, writer, packed, s_raw);
+        else if (out_side == 8) store_rows_to_host<8>(o.rgb8_host, c.W, tx * SAS_TILE + (qd & 1) * 8, ty * SAS_TILE + (qd >> 1) * 8,
+                                                      ox & 7, oy & 7, writer, packed, s_raw);
+    }
     if (WANT_MAX) store_tile_max(f, QUAD ? 4 * tile + qd : tile, ED, s_wmax);   // QUAD: one slot per quadrant (k_depth_tail reduces 4 x tiles)
     if (tid == 0 && qd == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
 #ifdef SAS_TUNE_WGTIME
