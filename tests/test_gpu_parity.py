@@ -871,3 +871,61 @@ def test_per_view_pose_sets_of_vectorised_envs(rasterizer):
     with pytest.raises(Exception):
         rasterizer.render_batch(Vs, Ks, 160, 120, BG, pose_sets=sets, pose_set=[9] * (2 * E))
 
+
+
+@pytest.mark.parametrize("quad", ["0", "1"])
+def test_tile_kernel_delivers_complete_tile_frames_to_the_host(monkeypatch, quad):
+    """Frames wanted in pinned host memory whose tiles are all complete (W, H multiples of 16) are stored there by the
+    tile kernel itself -- a tile's rows packed in LDS, 16 bytes per lane (8 per lane for a quadrant in the quad
+    layout) -- instead of through a device frame and a copy kernel.  Both layouts forced, against the oracle: the Gym
+    camera size (240x320), 640x480, a launch group with per-view pose sets, the complete-ordering path (where in the quad
+    layout quadrant 0 hands out the whole tile and its siblings nothing), an overflowing frame (rendered again), and the
+    sizes that must NOT take this path (ragged image, pageable destination) beside it."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_QUAD", quad)
+    r = Rasterizer("cuda:0")
+    try:
+        G = 5
+        sc = make_scene(25000, seed=4242, log_scale_mean=float(np.log(0.03)), n_groups=G)
+        _upload(r, sc, group_id=sc.group_id, n_groups=G)
+        sets = np.stack([random_group_poses(G, seed=70 + e) for e in range(2)])
+        for (W, H, f) in ((320, 240, 262.0), (640, 480, 500.0), (200, 136, 170.0)):
+            cams = [ring_camera(W, H, f, yaw_deg=y, elev=e) for y, e in ((0.0, 0.0), (70.0, 0.3), (140.0, -0.2))]
+            Vs, Ks = np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams])
+            idx = [0, 1, 1]
+            host = r.render_batch_host(Vs, Ks, W, H, BG, pose_sets=sets, pose_set=idx)
+            pageable = torch.zeros((3, H, W, 3), dtype=torch.uint8)
+            r.render_batch_host(Vs, Ks, W, H, BG, out=pageable, pose_sets=sets, pose_set=idx)
+            for v, c in enumerate(cams):
+                ref = oracle.render(sc.means, sc.opacities, sc.sh, c.viewmat, c.K, W, H, quats=sc.quats, scales=sc.scales, sh_degree=3,
+                                    group_id=sc.group_id, group_Rt=sets[idx[v]], background=BG, want_rgb8=True)
+                assert np.array_equal(host[v].numpy(), ref["rgb8"]), (W, H, v)
+                assert np.array_equal(pageable[v].numpy(), ref["rgb8"]), (W, H, v, "pageable")
+            one = r.render_batch_host(Vs[2:3], Ks[2:3], W, H, BG, pose_sets=sets, pose_set=[1])      # a single frame, not a group
+            assert torch.equal(one[0], host[2])
+        # a crowded depth bucket on top of a wide depth range: the complete ordering
+        rng = np.random.default_rng(5)
+        flat = make_scene(6000, seed=613, log_scale_mean=float(np.log(0.03)))
+        flat.means[:3000, 2] = 0.25
+        flat.means[:3000, :2] = rng.uniform(-0.35, 0.35, size=(3000, 2)).astype(np.float32)
+        flat.means[3000:] = np.stack([rng.uniform(-0.5, 0.5, 3000), rng.uniform(-0.5, 0.5, 3000), rng.uniform(-2.5, 2.0, 3000)], 1).astype(np.float32)
+        flat.opacities[:] = np.clip(flat.opacities, 0.004, 0.03)
+        _upload(r, flat)
+        cam = ring_camera(64, 48, 60.0)
+        out = r.render_batch_host(cam.viewmat[None], cam.K[None], 64, 48, BG)
+        assert r.stats()["fallback_tiles"] > 0
+        assert np.array_equal(out[0].numpy(), oracle.render_scene(flat, cam, background=BG, want_rgb8=True)["rgb8"])
+    finally:
+        r.close()
+    # an overflowing frame is rendered again and delivered again
+    r = Rasterizer("cuda:0")
+    try:
+        big = make_scene(30000, seed=444, log_scale_mean=float(np.log(0.12)))
+        _upload(r, big)
+        bc = ring_camera(640, 480, 500.0, yaw_deg=90.0)
+        out = r.render_batch_host(bc.viewmat[None], bc.K[None], 640, 480, BG)
+        assert r.stats()["regrows"] >= 1
+        assert np.array_equal(out[0].numpy(), oracle.render_scene(big, bc, background=BG, want_rgb8=True)["rgb8"])
+    finally:
+        r.close()
