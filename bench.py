@@ -142,7 +142,8 @@ def self_launch(n, argv, dry_run):
     Returns the child's exit code; its stdout (rank 0's JSON line) is passed through."""
     import socket
     import subprocess
-    if not dry_run and torch.cuda.device_count() < n:   # (device_count does not initialise the GPU)
+    rehearsal = "SAS_FORCE_DEVICE" in os.environ   # all ranks on one GPU (gloo): the multi-rank path on a 1-GPU box
+    if not dry_run and not rehearsal and torch.cuda.device_count() < n:   # (device_count does not initialise the GPU)
         print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as so:

@@ -584,6 +584,29 @@ def test_c_abi_error_paths_and_timing_means():
         r.set_group_poses(np.zeros((2, 12), np.float32))                             # scene has no groups
     with pytest.raises(ValueError):
         r.render(cam.viewmat, cam.K, 64, 48, out={"rgb": torch.empty((48, 64, 3), device="cuda:0", dtype=torch.float16)})
+    # round-3 entry points: pose sets / link poses on a scene without splat groups, link poses before their constants
+    V1, K1, bgf = np.ascontiguousarray(cam.viewmat[None], np.float32), np.ascontiguousarray(cam.K[None], np.float32), np.asarray(BG, np.float32)
+    idx, rt = np.zeros(1, np.int32), np.zeros((1, 12), np.float32)
+    out8 = torch.empty((1, 48, 64, 3), dtype=torch.uint8, device="cuda:0")
+    rc = L.sas_render_batch_posed(r._ctx, 1, V1.ctypes.data, K1.ctypes.data, idx.ctypes.data, 1, rt.ctypes.data, 64, 48, bgf.ctypes.data, 0,
+                                  None, None, None, out8.data_ptr(), None)
+    assert rc == -1 and b"no splat groups" in L.sas_last_error(r._ctx)
+    q1, p1 = np.array([[1.0, 0, 0, 0]]), np.zeros((1, 3))
+    assert L.sas_set_link_poses(r._ctx, 1, q1.ctypes.data, p1.ctypes.data, None) == -1 and b"sas_set_link_constants" in L.sas_last_error(r._ctx)
+    w4, x3 = np.zeros(4), np.zeros(3)
+    assert L.sas_link_attached_frame(r._ctx, q1.ctypes.data, p1.ctypes.data, p1.ctypes.data, w4.ctypes.data, x3.ctypes.data) == -1
+    eye = np.eye(3)
+    assert L.sas_set_link_constants(r._ctx, 1, 1.0, eye.ctypes.data, x3.ctypes.data, eye.ctypes.data, x3.ctypes.data, None, None) == -1   # more links than groups
+    gs = make_scene(400, seed=8, log_scale_mean=float(np.log(0.05)), n_groups=3)
+    _upload(r, gs, group_id=gs.group_id, n_groups=3)
+    bad = np.array([5], np.int32)
+    rc = L.sas_render_batch_posed(r._ctx, 1, V1.ctypes.data, K1.ctypes.data, bad.ctypes.data, 1, np.zeros((1, 3, 12), np.float32).ctypes.data, 64, 48,
+                                  bgf.ctypes.data, 0, None, None, None, out8.data_ptr(), None)
+    assert rc == -1 and b"pose_set[0]=5" in L.sas_last_error(r._ctx)
+    grp = np.array([7], np.int32)
+    assert L.sas_set_link_constants(r._ctx, 1, 1.0, eye.ctypes.data, x3.ctypes.data, eye.ctypes.data, x3.ctypes.data, None, grp.ctypes.data) == -1
+    assert L.sas_render_cameras_host(r._ctx, 1, None, None, 1.0, 64, 48, bgf.ctypes.data, 0, out8.data_ptr(), None) == -1
+    _upload(r, sc)
     # the context is still usable after every failure
     a = r.render(cam.viewmat, cam.K, 64, 48, BG, want=("rgb",))["rgb"].cpu().numpy()
     ref = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, 64, 48, quats=sc.quats, scales=sc.scales, background=BG)
