@@ -337,8 +337,11 @@ def main():
                        "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy") if a.config == 3 else None,
-                         "frac_is": "co-resident: the launch duration inside the timed region, where ~2.7 kernels share the chip "
-                                    "(2 launches x kernel_ms > ms_per_step); frac_isolated is the same bytes over the kernel alone on the GPU",
+                         "frac_is": "co-resident: the launch duration inside the timed region, where `tile_kernels_in_flight` launches of this "
+                                    "kernel (launches per step x kernel_ms / ms_per_step) plus the next frames' binning share the chip; the same "
+                                    "frames/s occurs with 0.24 ms and with 0.41 ms launches (DESIGN.md s6); frac_isolated is the same bytes over "
+                                    "the kernel alone on the GPU",
+                         "tile_kernels_in_flight": (V / per_launch) * blend_s * 1e3 / ms_per_step if V else 0.0,
                          "kernel_ms": blend_s * 1e3, "kernel_launches_timed": timed_frames, "views_per_kernel_launch": per_launch,
                          "step_algorithmic_bytes": step_bytes, "frame_algorithmic_GBps": step_gbps,
                          "frame_frac": step_gbps / HBM_PEAK_GBPS},

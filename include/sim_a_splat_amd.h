@@ -178,10 +178,12 @@ int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const flo
 /*
  * sas_render_batch for frames that are wanted on the HOST: get_render returns np.uint8 arrays
  * (splat_handler.py:339-344, splat_env_wrapper.py:148-157).  rgb8_host [n_views,H,W,3] is HOST memory (pinned --
- * hipHostMalloc, torch pin_memory -- for speed; pageable memory works through the runtime's staging).  The
- * frames are rendered into a staging buffer of the context and copied out on the frames' own streams right
- * behind the tile kernels, so the call returns with the pixels in place and no second round trip (device-to-host
- * copy issued by the caller after the frame) is needed.  Blocking only (SAS_ASYNC is rejected).
+ * hipHostMalloc, torch pin_memory -- for speed; pageable memory works through the runtime's staging).  When
+ * width and height are multiples of 16 and the destination is pinned, the tile kernel stores each finished tile
+ * straight into rgb8_host (its rows packed in LDS, 16 B per lane); otherwise the frames are rendered into a
+ * staging buffer of the context and copied out on the frames' own streams right behind the tile kernels.  Either
+ * way the call returns with the pixels in place and no second round trip (device-to-host copy issued by the
+ * caller after the frame) is needed.  Blocking only (SAS_ASYNC is rejected).
  */
 int sas_render_batch_host(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                           const float *background, unsigned flags, uint8_t *rgb8_host, void *stream);

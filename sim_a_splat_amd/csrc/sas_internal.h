@@ -105,8 +105,12 @@ struct SasParams {
 
 // Up to SAS_MAX_GROUP same-sized views rendered by ONE set of launches: the cameras of a Gym step.  Passed to the
 // *_multi kernels by value.
+#ifndef SAS_MULTI_INLINE_ROWS
 #define SAS_MULTI_INLINE_ROWS 32   // pose rows (all views together) a launch group carries in its argument segment
+#endif
+#ifndef SAS_PROJ_INLINE_ROWS
 #define SAS_PROJ_INLINE_ROWS 16    // ... a single view / a view pair
+#endif
 struct SasMulti {
     SasFrame f[SAS_MAX_GROUP];
     SasParams P[SAS_MAX_GROUP];

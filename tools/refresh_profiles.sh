@@ -23,6 +23,8 @@ if [ "${1:-}" = "--install" ]; then
   cp $src/ramp.txt profiles/${tag}_clock_ramp.txt
   cp $src/timeline_driver_cmd.txt profiles/${tag}_timeline_driver_cmd.txt
   cp $src/env_steps.txt profiles/${tag}_env_steps.txt
+  [ -f $src/gpu_tests.log ] && cp $src/gpu_tests.log profiles/${tag}_gpu_tests.log
+  [ -f $src/bounds_tests.log ] && cp $src/bounds_tests.log profiles/${tag}_bounds_build_gpu_tests.log
   python tools/collect_traffic.py profiles/${tag}_pmc_fetch_size.csv profiles/${tag}_pmc_write_size.csv profiles/hbm_traffic.json > /dev/null
   python tools/collect_insts.py $(find $src/pmc_insts_bench -name "*counter_collection.csv" | head -n 1) $src/blend_stats.txt profiles/tile_insts.json
   ls -la profiles
