@@ -1209,6 +1209,9 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     if (end > f.cap) end = f.cap;
     const int n = (int)(end - beg);
     const unsigned long long *g = f.keys + beg;
+    // the tile kernel's waves issue ahead of the co-resident binning waves of the next frames (+1.2 % frames/s at config 3:
+    // what a step costs is the tile kernel's slot time; the reverse priority costs 0.5 %)
+    __builtin_amdgcn_s_setprio(3);
 
     if (n > 0 && n <= CH) {
         // ---- short list: one pass, keys loaded once into registers, whole list is the chunk

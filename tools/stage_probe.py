@@ -18,6 +18,7 @@ ap.add_argument("--cfg", type=int, default=3)
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--fast-exp", action="store_true")
+ap.add_argument("--plain", action="store_true", help="no stage events: blocking frames as a caller issues them (wall time per frame)")
 a = ap.parse_args()
 sc, cams = config_scene_and_cameras(a.cfg, a.scale)
 cam = cams[0]
@@ -27,6 +28,13 @@ r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_deg
 print("upload s", time.time() - t0, flush=True)
 out = None
 acc = {}
+if a.plain:
+    for i in range(a.frames + 20):
+        if i == 20:
+            t0 = time.perf_counter()
+        out = r.render(cam.viewmat, cam.K, cam.width, cam.height, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",), out=out)
+    print(json.dumps({"cfg": a.cfg, "us_per_blocking_frame": (time.perf_counter() - t0) / a.frames * 1e6}))
+    sys.exit(0)
 for i in range(a.frames + 2):
     out = r.render(cam.viewmat, cam.K, cam.width, cam.height, NERFSTUDIO_EVAL_BACKGROUND, want=("rgb",),
                    timing=True, fast_exp=a.fast_exp, out=out)
