@@ -11,6 +11,7 @@ upstream); the inner env is a stand-in that only produces the draw messages join
 from __future__ import annotations
 
 import argparse
+import gc
 import sys
 import time
 import types
@@ -76,6 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--no-gc-freeze", action="store_true", help="leave Python's collector as it is (one ~40 ms pause inside the loop)")
     a = ap.parse_args()
 
     sc = make_scene(113_831, seed=2, n_groups=N_LINKS + 1)            # group 0 = static scene
@@ -96,6 +98,12 @@ def main():
     for _ in range(600):                                               # warm-up (and one cycle of the stand-in's messages)
         obs, *_ = env.step(None)
     torch.cuda.synchronize()
+    if not a.no_gc_freeze:
+        # One full collection over the objects torch's import leaves behind is a ~40 ms pause that falls, once, somewhere
+        # around the 1000th step of a process (tools/slow_state_probe.py): 10 % of a 2000-step measurement, nothing of a
+        # training run.  Freezing what exists after set-up keeps it out of the loop.
+        gc.collect()
+        gc.freeze()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         obs, reward, terminated, truncated, info = env.step(None)      # {"robot_pos", "camera_0": u8[3,240,320], "camera_1"}

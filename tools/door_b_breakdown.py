@@ -1,5 +1,5 @@
 """Where an env step of the Door-B loop spends its host time (113,831 Gaussians, 8 groups, 2 cameras 240x320)."""
-import sys, time
+import gc, sys, time
 from pathlib import Path
 import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -13,6 +13,7 @@ V = np.stack([c.viewmat for c in cams]); K = np.stack([c.K for c in cams])
 poses = [random_group_poses(8, seed=s) for s in range(300)]
 host = torch.empty((2, 240, 320, 3), dtype=torch.uint8).pin_memory()
 acc = {"poses": 0.0, "render": 0.0, "copy": 0.0}
+gc.collect(); gc.freeze()   # a full collection over torch's objects pauses ~40 ms, once, around the 1000th step (tools/slow_state_probe.py)
 for it in range(2):
     acc = {k: 0.0 for k in acc}
     t_all = time.perf_counter()
