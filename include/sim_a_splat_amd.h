@@ -59,12 +59,16 @@ enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path onl
        SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* depth fill */,
        SAS_T_TOTAL, SAS_T_COUNT };
 
-/* sas_frame_stats slots (int64) of the last completed frame */
+/* sas_frame_stats slots (int64) of the last completed frame.  SAS_S_NISECT counts Gaussian x 16-pixel-tile intersections
+ * (gsplat's isect count) whatever the frame's own binning; SAS_S_NKEYS what the frame actually binned (the same number,
+ * except in the quad layout, which bins in 8-pixel tiles); SAS_S_MAX_TILE_LEN is the longest list of the frame's own tiles. */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
        SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */,
-       SAS_S_QUAD_LAYOUT /* 1: the frame's tile kernel ran in its quad layout (four workgroups per tile) */,
-       SAS_S_LAUNCH_VIEWS /* views that shared the frame's launches (1, or the size of its launch group) */, SAS_S_COUNT };
+       SAS_S_QUAD_LAYOUT /* 1: the frame ran in the quad layout (views of a few hundred tiles): binned in 8-pixel tiles, one
+                            workgroup per 8x8 quadrant with one wave per 4x4 block */,
+       SAS_S_LAUNCH_VIEWS /* views that shared the frame's launches (1, or the size of its launch group) */,
+       SAS_S_NKEYS /* intersection keys written at the frame's own tile size */, SAS_S_COUNT };
 
 /* Create / destroy a rasterizer context on HIP device `device`. */
 int sas_create(int device, sas_ctx **out);

@@ -23,7 +23,7 @@ SAS_FULL_SORT = 16
 SAS_TIME_TILES = 32
 
 STAGE_NAMES = ("project", "scan", "scatter", "sort", "blend", "tail", "total")
-STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles", "quad_layout", "launch_views")
+STAT_NAMES = ("n_visible", "n_isect", "max_tile_len", "capacity", "regrows", "window_misses", "fallback_tiles", "quad_layout", "launch_views", "n_keys")
 
 # every symbol include/sim_a_splat_amd.h declares
 EXPORTS = (

@@ -119,7 +119,7 @@ struct sas_ctx {
     static constexpr int64_t kPairMinGaussians = 500000;
     uint64_t scene_version = 0;
     int64_t frames_submitted = 0, frames_completed = 0;   // sas_frames_completed
-    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t stats[SAS_S_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int64_t regrows = 0;
     float stage_ms[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     double stage_sum[SAS_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
@@ -223,7 +223,7 @@ void storage_order(int64_t n, const float *means, const uint8_t *gid, std::vecto
 }
 
 // Camera constants in the oracle's operation order (oracle/sas_oracle.c cam_from, project_one).
-void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
+void make_cam(const float *V, const float *K, int W, int H, int tile_px, SasCam &c)
 {
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) c.R[3 * i + j] = V[4 * i + j];
@@ -235,8 +235,9 @@ void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
     }
     c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
     c.W = W; c.H = H;
-    c.tw = (W + SAS_TILE - 1) / SAS_TILE;
-    c.th = (H + SAS_TILE - 1) / SAS_TILE;
+    c.tile_px = tile_px;
+    c.tw = (W + tile_px - 1) / tile_px;
+    c.th = (H + tile_px - 1) / tile_px;
     c.Wf = (float)W; c.Hf = (float)H;
     const float tan_fovx = (0.5f * c.Wf) / c.fx;
     const float tan_fovy = (0.5f * c.Hf) / c.fy;
@@ -245,6 +246,8 @@ void make_cam(const float *V, const float *K, int W, int H, SasCam &c)
     c.lim_y_pos = fmaf(0.3f, tan_fovy, (c.Hf - c.cy) / c.fy);
     c.lim_y_neg = fmaf(0.3f, tan_fovy, c.cy / c.fy);
 }
+
+static size_t f_wg_stride(const sas_ctx *c) { return (size_t)((c->scene.n + 255) / 256 + 1); }
 
 SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
 {
@@ -269,6 +272,7 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.sorted_ids = (int *)q.ids.p;
     f.cap = q.cap;
     f.wg_vis = (int *)q.wgvis.p;
+    f.wg_isect16 = sl.quad ? (int *)q.wgvis.p + f_wg_stride(c) : nullptr;
     f.tile_max = (unsigned *)q.tilemax.p;
     f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
     f.group_host = c->scene.n_groups > 0 ? sl.poses_host : nullptr;
@@ -324,7 +328,11 @@ int enqueue_poses(sas_ctx *c, Slot *const *sl, int n, hipStream_t st, bool multi
 int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
 {
     const RenderArgs &a = sl.args;
-    make_cam(a.viewmat, a.K, a.W, a.H, sl.cam);
+    // The layout is a property of the whole frame: in the quad layout the view is BINNED in 8-pixel tiles (every 8x8
+    // quadrant has its own list), so the choice is made here, in front of the projection.
+    const int tiles16 = ((a.W + SAS_TILE - 1) / SAS_TILE) * ((a.H + SAS_TILE - 1) / SAS_TILE);
+    sl.quad = use_quad(c, tiles16, a.flags);
+    make_cam(a.viewmat, a.K, a.W, a.H, sl.quad ? SAS_TILE / 2 : SAS_TILE, sl.cam);
     const SasCam &cam = sl.cam;
     const int tiles = cam.tw * cam.th;
     const int64_t n = c->scene.n;
@@ -349,9 +357,9 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
             q.counters_zero = true;
         }
     }
-    if ((rc = ensure(c, q.wgvis, sizeof(int) * (size_t)((n + 255) / 256 + 1)))) return rc;
+    if ((rc = ensure(c, q.wgvis, sizeof(int) * 2 * f_wg_stride(c)))) return rc;   // visible counts | 16-pixel intersections (quad layout)
     if ((rc = ensure(c, q.wgbase, sizeof(int) * SAS_WIN_BINS * (size_t)((n + 255) / 256 + 1)))) return rc;
-    if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * 4 * (size_t)tiles))) return rc;   // x 4: one slot per quadrant in the quad layout
+    if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
     if (c->scene.n_groups > 0 && (rc = ensure(c, sl.poses_dev, sizeof(float) * 12 * 256))) return rc;
@@ -416,14 +424,13 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
-    const bool quad = !full && use_quad(c, tiles, a.flags);
-    sl.quad = quad;
+    const bool quad = sl.quad;   // (prepare_frame; never for SAS_FULL_SORT frames)
     if (full) sas_launch_blend(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill);
     else sas_launch_tiles_lazy(st, c->scene, tiles, P, f, (a.flags & SAS_FAST_EXP) != 0, fill, quad,
                                ttiles ? sl.ev[4] : nullptr, ttiles ? sl.ev[5] : nullptr);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[5], st));
     const bool pts = a.depth && (a.points || a.mask);
-    if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, P, f, fill, pts);
+    if (fill || pts) sas_launch_depth_tail(st, tiles, P, f, fill, pts);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[6], st));
     if (a.rgb8_host && a.rgb8 && !sl.host_direct) {   // frame wanted on the host and not delivered by the tile kernel: by a copy kernel when the destination is pinned (no copy-engine hop)
         const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
@@ -473,15 +480,14 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
-    const bool quad = use_quad(c, tiles, a.flags);   // by the size of one view: groups of four 300-tile views still gain (vec_env_probe)
-    for (int k = 0; k < n; ++k) sl[k]->quad = quad;
+    const bool quad = ld.quad;   // by the size of one view (prepare_frame): groups of four 300-tile views still gain (vec_env_probe)
     sas_launch_tiles_lazy_multi(st, c->scene, tiles, mf, (a.flags & SAS_FAST_EXP) != 0, any_fill, quad,
                                 ttiles ? ld.ev[4] : nullptr, ttiles ? ld.ev[5] : nullptr);
     for (int k = 0; k < n; ++k) {
         const RenderArgs &ak = sl[k]->args;
         const bool fill = ak.depth && (ak.flags & SAS_DEPTH_FILL_MAX);
         const bool pts = ak.depth && (ak.points || ak.mask);
-        if (fill || pts) sas_launch_depth_tail(st, quad ? 4 * tiles : tiles, mf.P[k], mf.f[k], fill, pts);
+        if (fill || pts) sas_launch_depth_tail(st, tiles, mf.P[k], mf.f[k], fill, pts);
     }
     {   // frames wanted on the host (sas_render_batch_host): by a kernel when the destination is pinned
         const size_t fb = 3 * (size_t)a.W * (size_t)a.H;
@@ -537,7 +543,8 @@ int complete_oldest(sas_ctx *c)
         for (int k = 0; k < g; ++k) {
             const volatile unsigned *s = mem[k]->stats_host;   // written by the projection's tail (+ the tile kernel's [6])
             c->stats[SAS_S_NVISIBLE] = s[0];
-            c->stats[SAS_S_NISECT] = s[1];
+            c->stats[SAS_S_NISECT] = s[3];   // intersections with the contract's 16-pixel tiles ([1]: keys written, at the frame's own binning)
+            c->stats[SAS_S_NKEYS] = s[1];
             c->stats[SAS_S_MAX_TILE_LEN] = s[4];
             c->stats[SAS_S_CAPACITY] = mem[k]->scr.cap;
             c->stats[SAS_S_REGROWS] = c->regrows;

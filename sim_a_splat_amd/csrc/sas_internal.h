@@ -13,7 +13,8 @@ struct SasCam {
     float fx, fy, cx, cy;
     float lim_x_pos, lim_x_neg, lim_y_pos, lim_y_neg;
     float Wf, Hf;
-    int W, H, tw, th;
+    int W, H, tw, th;      // tw x th tiles of tile_px pixels
+    int tile_px;           // SAS_TILE; 8 in the quad layout, whose 8x8 quadrants are binned as tiles of their own
 };
 
 // Scene in HBM.  At upload the Gaussians are re-ordered along a 3-D Hilbert curve (per splat
@@ -43,7 +44,8 @@ struct SasScene {
 //   tickets        [65 * 32] words: 64 sub-tickets (one cache line each) + the master ticket of the projection's
 //                  workgroups (who is last?); each is reset by its last taker
 //   stats_host     PINNED host words the frame reports through, written by the projection's tail (no copy at the
-//                  end of a frame): [0] n_visible [1] n_isect [2] overflow [4] max tile length [5] window misses;
+//                  end of a frame): [0] n_visible [1] keys written (= n_isect at 16-pixel binning) [2] overflow [3] n_isect of the contract's 16-pixel
+//                  tiles (quad layout) [4] max tile length [5] window misses;
 //                  [6] tiles the lazy kernel had to order completely (one depth bucket > chunk): zeroed by the tail,
 //                  counted by the tile kernel with a system-scope atomic (rare)
 // INVARIANT: tile_count[] and tile_big[] are all zero between frames -- the tile kernel (k_blend on the full path)
@@ -72,7 +74,9 @@ struct SasFrame {
     unsigned *tickets;         // [65 * 32]
     unsigned *stats_host;      // [8] pinned
     int *wg_vis;               // [ceil(n/256)] visible Gaussians per projection workgroup
-    unsigned *tile_max;        // [4 * tiles] per-tile (quad layout: per-quadrant) max expected depth (bits), written when depth is filled
+    int *wg_isect16;           // quad layout (8-pixel binning) only, else nullptr: [ceil(n/256)] intersections with the 16-pixel
+                               // tiles of the contract per projection workgroup (the n_isect the frame reports)
+    unsigned *tile_max;        // [tiles] per-tile max expected depth (bits), written when depth is filled
     const float *group_Rt;     // [n_groups,12] poses of the splat groups for THIS view (device), or nullptr
     const float *group_host;   // the same rows on the host (the slot's pinned snapshot): small pose blocks ride in the
                                // projection's argument segment instead of being uploaded (sas_poses_inline)

@@ -245,7 +245,7 @@ DEV void project_view(const SasCam &c, const float *cov, float op, float x, floa
     if (!keep) return;
     g.vis = true;
     // T3 tile rectangle
-    const float ts = (float)SAS_TILE;
+    const float ts = (float)c.tile_px;   // 16, or 8 (quad layout): powers of two, so the 8-pixel rectangle halves to the 16-pixel one exactly
     const float trx = rx / ts, try_ = ry / ts;
     const float ttx = mx / ts, tty = my / ts;
     const float twf = (float)c.tw, thf = (float)c.th;
@@ -302,13 +302,22 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
                   [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); the projection's tail adds the per-workgroup counts up
-    if (threadIdx.x == 0) *s_nvis = 0;
+    if (threadIdx.x == 0) { s_nvis[0] = 0; s_nvis[1] = 0; }
     __syncthreads();
     const unsigned long long vb = __ballot(vis);
-    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(s_nvis, (int)__popcll(vb));
+    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis[0], (int)__popcll(vb));
+    if (f.wg_isect16) {   // (uniform) 8-pixel binning: the frame still reports the intersections with the contract's 16-pixel tiles
+        int a16 = vis ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) a16 += __shfl_xor(a16, d);
+        if ((threadIdx.x & 63) == 0 && a16) atomicAdd(&s_nvis[1], a16);
+    }
     __syncthreads();
     // (an agent-scope store: written through to where the tail workgroup, possibly on another XCD, reads it)
-    if (threadIdx.x == 0) __hip_atomic_store(&f.wg_vis[blockIdx.x], *s_nvis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&f.wg_vis[blockIdx.x], s_nvis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.wg_isect16) __hip_atomic_store(&f.wg_isect16[blockIdx.x], s_nvis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- the projection's tail (T5): offsets, cursors, list-length classes, statistics -----------------------------------
@@ -338,8 +347,10 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
     s_bins[tid] = 0;
     s_bins[256 + tid] = 0;
     // ---- phase 1: totals (bursts of 16 tiles: 2 x 4 16-byte loads in flight, 32 registers)
-    int nvis = 0;
+    int nvis = 0, n16 = 0;
     for (int i = tid; i < f.n_wg; i += 256) nvis += f.wg_vis[i];
+    if (f.wg_isect16)
+        for (int i = tid; i < f.n_wg; i += 256) n16 += f.wg_isect16[i];
     int total = 0, maxlen = 0;
     for (int k0 = 0; k0 < per; k0 += 16) {
         int4 c[4], g[4];
@@ -366,15 +377,17 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
     for (int d = 32; d > 0; d >>= 1) {
         maxlen = max(maxlen, __shfl_xor(maxlen, d));
         nvis += __shfl_xor(nvis, d);
+        n16 += __shfl_xor(n16, d);
     }
     if (lane == 63) s_w[wv] = incl;
-    if (lane == 0) { s_w[4 + wv] = maxlen; s_w[8 + wv] = nvis; }
+    if (lane == 0) { s_w[4 + wv] = maxlen; s_w[8 + wv] = nvis; s_w[12 + wv] = n16; }
     __syncthreads();
     int run = incl - total;
     for (int w = 0; w < wv; ++w) run += s_w[w];
     const int carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     const int maxlen_all = max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
     const int nvis_all = s_w[8] + s_w[9] + s_w[10] + s_w[11];
+    const int n16_all = s_w[12] + s_w[13] + s_w[14] + s_w[15];
     // ---- phase 2: offsets, cursors of the `big` entries, class sizes
     for (int k0 = 0; k0 < per; k0 += 16) {
         int4 c[4], g[4];
@@ -432,7 +445,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
         h[0] = (unsigned)nvis_all;
         h[1] = (unsigned)carry;
         h[2] = (long long)carry > f.cap ? 1u : 0u;
-        h[3] = 0u;
+        h[3] = f.wg_isect16 ? (unsigned)n16_all : (unsigned)carry;   // intersections with the contract's 16-pixel tiles
         h[4] = (unsigned)maxlen_all;
         h[5] = f.stats[5];
         h[6] = 0u;
@@ -602,9 +615,9 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     }
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
-    __shared__ int s_nvis;
+    __shared__ int s_nvis[2];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], s_win, s_hist, &s_nvis);
+    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], s_win, s_hist, s_nvis);
     // ---- the last workgroup to get here scans the counts of the frame(s).
     // Everything the tail reads from other workgroups was written by AGENT-scope atomics (the per-tile counts, the
     // window-miss counter, wg_vis below), which are performed at the point all XCDs share; what remains is ordering:

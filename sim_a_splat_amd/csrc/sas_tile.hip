@@ -212,47 +212,6 @@ DEV void sort_global_bitonic(unsigned long long *g, int *out, int n, const int *
     for (int i = tid; i < n; i += nthreads) out[i] = (int)lo32(g[i]);
 }
 
-// The same network on storage SLOTS: `ids` receives the low words of the (untouched) keys and is ordered in place by
-// (depth word of the slot, caller index); the depth words are gathered from the projection's info.  For the quad
-// layout, where the key segment must stay read-only (see tile_lazy_body).  A real call: rare path, keeps the
-// common one's registers.
-__device__ __attribute__((noinline)) void sort_ids_bitonic(const unsigned long long *g, int *ids, int n, const uint4 *info, const int *perm)
-{
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    for (int i = tid; i < n; i += nthreads) ids[i] = (int)lo32(g[i]);
-    __threadfence_block();
-    __syncthreads();
-    auto greater = [&](int a, int b) {
-        const unsigned da = info[a].z, db = info[b].z;
-        return da != db ? da > db : perm[a] > perm[b];
-    };
-    int P = 2;
-    while (P < n) P <<= 1;
-    for (int k = 2; k <= P; k <<= 1) {
-        const int hk = k >> 1;
-        for (int p = tid; p < (P >> 1); p += nthreads) {
-            const int blk = (p / hk) * k, o = p % hk;
-            const int l = blk + o, r = blk + k - 1 - o;
-            if (r < n) {
-                const int a = ids[l], b = ids[r];
-                if (greater(a, b)) { ids[l] = b; ids[r] = a; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int p = tid; p < (P >> 1); p += nthreads) {
-                const int l = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int r = l | j;
-                if (r < n) {
-                    const int a = ids[l], b = ids[r];
-                    if (greater(a, b)) { ids[l] = b; ids[r] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // ================================================================================================
 // Full path, stage 1: k_sort_* write every tile's complete front-to-back list (storage slots)
 // ================================================================================================
@@ -1182,20 +1141,26 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();
 #endif
-    // QUAD: four workgroups per tile, one per 8x8 quadrant (pixel_of_quad)
-    const int tile = f.tile_order[QUAD ? (wg >> 2) : wg];
-    const int qd = QUAD ? (int)(wg & 3u) : 0;
+    // QUAD: the frame is binned in 8-pixel tiles (c.tile_px == 8): this workgroup's tile is the 8x8 quadrant qd of the
+    // contract's 16-pixel tile (tx, ty), whose origin the sigma polynomials refer to (pixel_of_quad); the list is its own
+    const int tile = f.tile_order[wg];
     if (!SAS_IN(tile, f.n_tiles, 213)) return;   // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx = tile % c.tw, ty = tile / c.tw;
+    int tx = tile % c.tw, ty = tile / c.tw;
+    int qd = 0;
+    if (QUAD) {
+        qd = (tx & 1) | ((ty & 1) << 1);
+        tx >>= 1;
+        ty >>= 1;
+    }
     int ox, oy;
     if (QUAD) pixel_of_quad(qd, wv, lane, ox, oy);
     else pixel_of(wv, lane, ox, oy);
     int ix = tx * SAS_TILE + ox, iy = ty * SAS_TILE + oy;
     PixConst pc = pix_const(ox, oy);
     bool inside = ix < c.W && iy < c.H;
-    bool writer = !QUAD || (lane & 3) == 0;   // QUAD: the four lanes of a pixel hold the same state, one stores it
-    int out_side = QUAD ? 8 : 16;             // what this workgroup hands out: its quadrant, the whole tile, or (0) nothing
+    const bool writer = !QUAD || (lane & 3) == 0;   // QUAD: the four lanes of a pixel hold the same state, one stores it
+    const int out_side = QUAD ? 8 : 16;       // what this workgroup hands out: its quadrant or the whole tile
     PixState p = pix_init(inside, ox);
     bool wdone = __all(!inside);
     // composite `count` ordered entries in this kernel's layout
@@ -1319,12 +1284,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         }
         __syncthreads();
         int b_next = 0;
-        // QUAD: a tile's four workgroups share its global segments and are not synchronised with each other, so
-        // every one of them treats the KEY segment as read-only for the whole kernel: the decision for the complete
-        // ordering is taken here, from the histogram of keys nobody changes (all four arrive at the same answer);
-        // quadrant 0 alone then renders such a tile (in the ordinary layout), ordering storage slots in the id
-        // segment -- which only it touches -- by the depth words of the projection's info; the others leave.
-        bool bail = QUAD ? (bool)__syncthreads_or(s_hist[tid] > (unsigned)CH) : false;
+        bool bail = false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
         int p_consumed = 0;                       // ... and this many of them have been composited since
         int *const ids = f.sorted_ids + beg;      // ... as storage slots in the tile's (otherwise unused) id segment
@@ -1375,7 +1335,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             //      chunk instead of scanning the whole list again (n^2 / 512 key reads on a long translucent list;
             //      only worth it when many rounds are still to come: kPartitionMin).
             //      Bucket t of the remainder starts at the exclusive count of buckets b_next .. t - 1: the scan above.
-            if (!QUAD && !partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {   // (the id segment is shared by a tile's four QUAD workgroups)
+            if (!partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
                 s_cur[tid] = my_incl - my_hv;
                 __syncthreads();
                 partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
@@ -1445,28 +1405,13 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         if (bail) {
             // More than CH entries in one depth bucket (e.g. thousands of coplanar splats): order
             // the whole segment in place (slow, rare) and composite it from scratch.
-            if (QUAD && qd != 0) {
-                writer = false;
-                out_side = 0;
-            } else {
-                if (tid == 0) __hip_atomic_fetch_add(&f.stats_host[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                int *out = f.sorted_ids + beg;
-                if (QUAD) sort_ids_bitonic(f.keys + beg, out, n, f.info, perm);
-                else sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
-                __syncthreads();
-                if (QUAD) {   // the whole tile, ordinary layout
-                    pixel_of(wv, lane, ox, oy);
-                    ix = tx * SAS_TILE + ox;
-                    iy = ty * SAS_TILE + oy;
-                    pc = pix_const(ox, oy);
-                    inside = ix < c.W && iy < c.H;
-                    writer = true;
-                    out_side = 16;
-                }
-                p = pix_init(inside, ox);
-                wdone = __all(!inside);
-                blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, n, [&](int i) { return (long long)(unsigned)out[i]; }, L, p, wdone);
-            }
+            if (tid == 0) __hip_atomic_fetch_add(&f.stats_host[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            int *out = f.sorted_ids + beg;
+            sort_global_bitonic(f.keys + beg, out, n, perm, tid, kLazyThreads);
+            __syncthreads();
+            p = pix_init(inside, ox);
+            wdone = __all(!inside);
+            blend(n, [&](int i) { return (long long)(unsigned)out[i]; });
         }
     }
     unsigned packed;
@@ -1476,8 +1421,8 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         else if (out_side == 8) store_rows_to_host<8>(o.rgb8_host, c.W, tx * SAS_TILE + (qd & 1) * 8, ty * SAS_TILE + (qd >> 1) * 8,
                                                       ox & 7, oy & 7, writer, packed, s_raw);
     }
-    if (WANT_MAX) store_tile_max(f, QUAD ? 4 * tile + qd : tile, ED, s_wmax);   // QUAD: one slot per quadrant (k_depth_tail reduces 4 x tiles)
-    if (tid == 0 && qd == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
+    if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
+    if (tid == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
 #ifdef SAS_TUNE_WGTIME
     if (tid == 0 && blockIdx.x < kDbgWgMax) {
         g_dbg_wg[3 * blockIdx.x] = t_wg0;
@@ -1653,8 +1598,8 @@ void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const S
         if (want_max) launch_lazy<true, true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
         else launch_lazy<true, false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
     } else if (quad) {
-        if (want_max) launch_lazy<false, true, true>(st, 4 * grid, P, f, n, s.perm, ev_start, ev_stop);
-        else launch_lazy<false, false, true>(st, 4 * grid, P, f, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy<false, true, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
+        else launch_lazy<false, false, true>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
     } else {
         if (want_max) launch_lazy<false, true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
         else launch_lazy<false, false, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
@@ -1673,14 +1618,14 @@ static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, lon
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
                                  bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid((unsigned)tiles * (unsigned)mf.nv), grid4(4u * (unsigned)tiles * (unsigned)mf.nv);   // views interleaved (k_tile_lazy_multi)
+    const dim3 grid((unsigned)tiles * (unsigned)mf.nv);   // views interleaved (k_tile_lazy_multi)
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
         if (want_max) launch_lazy_multi<true, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
         else launch_lazy_multi<true, false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
     } else if (quad) {
-        if (want_max) launch_lazy_multi<false, true, true>(st, grid4, mf, n, s.perm, ev_start, ev_stop);
-        else launch_lazy_multi<false, false, true>(st, grid4, mf, n, s.perm, ev_start, ev_stop);
+        if (want_max) launch_lazy_multi<false, true, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
+        else launch_lazy_multi<false, false, true>(st, grid, mf, n, s.perm, ev_start, ev_stop);
     } else {
         if (want_max) launch_lazy_multi<false, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
         else launch_lazy_multi<false, false, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);
