@@ -1079,6 +1079,9 @@ constexpr int kChunk = SAS_TUNE_CHUNK;   // entries ordered and composited per r
 #define SAS_TUNE_QCHUNK 1024
 #endif
 constexpr int kChunkQuad = SAS_TUNE_QCHUNK;   // ... in the quad layout
+#ifndef SAS_TUNE_QPART
+#define SAS_TUNE_QPART 1
+#endif
 #ifndef SAS_TUNE_RANKMAX
 #define SAS_TUNE_RANKMAX 32
 #endif
@@ -1335,7 +1338,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             //      chunk instead of scanning the whole list again (n^2 / 512 key reads on a long translucent list;
             //      only worth it when many rounds are still to come: kPartitionMin).
             //      Bucket t of the remainder starts at the exclusive count of buckets b_next .. t - 1: the scan above.
-            if (!partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
+            if ((!QUAD || SAS_TUNE_QPART) && !partitioned && b_next > 0 && s_rem > (unsigned)kPartitionMin) {
                 s_cur[tid] = my_incl - my_hv;
                 __syncthreads();
                 partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
