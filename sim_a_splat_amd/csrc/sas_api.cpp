@@ -72,7 +72,7 @@ struct Slot {
     SasCam cam{};
     SasParams params{};
     bool busy = false, timed = false, timed_tiles = false;
-    bool quad = false;   // the frame's tile kernel was launched in its quad layout
+    bool quad = false;   // the frame runs in the quad layout: projected, binned and composited in 8-pixel tiles (prepare_frame)
     bool host_direct = false;   // the tile kernel delivers the uint8 frame to pinned host memory itself
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
 };
@@ -109,8 +109,8 @@ struct sas_ctx {
     // sas_render_batch projects two views per pass over the scene when that pass is long enough to pay
     // (measured: +5 % frames/s at 1 M Gaussians, +16 % at 5 M, -5 % at 0.3 M).  SAS_PAIR=0/1 forces it.
     int pair_views = -1;            // -1: by scene size
-    // quad layout of the tile kernel (four workgroups per tile): -1 = for views of at most quad_max_tiles
-    // tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
+    // quad layout (the frame binned in 8-pixel tiles, one workgroup per 8x8 quadrant): -1 = for views of at most
+    // quad_max_tiles 16-pixel tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
     int quad_mode = -1;
     int quad_max_tiles = 640;
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym

@@ -178,8 +178,9 @@ void sas_launch_sort(hipStream_t st, const SasScene &s, int tiles, const SasFram
 void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasParams &P, const SasFrame &f,
                       bool fast_exp, bool want_max);
 // ev_start/ev_stop (optional): stamped with the kernel's own begin/end (hipExtLaunchKernelGGL).
-// quad: four workgroups per tile, one per 8x8 quadrant (small frames; sas_tiles_lazy_quad_ok says whether the
-// build has that layout for the requested exponential); tile_max then holds 4 x tiles entries.
+// quad: the frame was projected and binned in 8-pixel tiles (SasCam::tile_px == 8; `tiles` counts those): one workgroup
+// per 8x8 quadrant of a 16-pixel tile (small frames; sas_tiles_lazy_quad_ok says whether the build has that layout for
+// the requested exponential).
 bool sas_tiles_lazy_quad_ok(bool fast_exp);
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams &P, const SasFrame &f,
                            bool fast_exp, bool want_max, bool quad, hipEvent_t ev_start, hipEvent_t ev_stop);

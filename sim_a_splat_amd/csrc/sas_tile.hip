@@ -436,8 +436,8 @@ DEV void pixel_of(int wv, int lane, int &ox, int &oy)
     oy = (wv >> 1) * 8 + (g >> 1) * 4 + (q >> 2);
 }
 
-// ---- quad layout (k_tile_lazy_quad: frames of a few hundred tiles) --------------------------------
-// FOUR workgroups per tile, one per 8x8 quadrant qd = (qx, qy); wave w of a workgroup owns the quadrant's
+// ---- quad layout (k_tile_lazy<..., QUAD>: frames of a few hundred tiles, binned in 8-pixel tiles) ----
+// One workgroup per 8x8 quadrant qd = (qx, qy) of a 16-pixel tile, with the quadrant's own list; wave w of a workgroup owns the quadrant's
 // 4x4 block w; a lane is (pixel q = lane >> 2 of the block, entry slot e = lane & 3): the four lanes of a
 // DPP quad work on four consecutive queue entries of the SAME pixel.
 DEV void pixel_of_quad(int qd, int wv, int lane, int &ox, int &oy)
@@ -1577,9 +1577,8 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 }
 
 // Production path: lazy ordering + compositing of every tile in one launch.
-// quad: four workgroups per tile (pixel_of_quad), for frames of a few hundred tiles; exact exponential only
-// (SAS_FAST_EXP frames take the ordinary layout).  The caller sizes tile_max for 4 x tiles and passes 4 x tiles
-// to sas_launch_depth_tail when it chose quad.
+// quad: frames of a few hundred tiles, binned in 8-pixel tiles by their projection (`tiles` counts those): one
+// workgroup per 8x8 quadrant (pixel_of_quad); exact exponential only (SAS_FAST_EXP frames take the ordinary layout).
 template <bool FAST, bool WMAX, bool QUAD>
 static void launch_lazy(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n, const int *perm,
                         hipEvent_t e0, hipEvent_t e1)

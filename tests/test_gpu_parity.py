@@ -680,14 +680,15 @@ def test_frames_delivered_to_host_memory(monkeypatch, group):
 
 @pytest.mark.parametrize("quad", ["0", "1"])
 def test_both_tile_kernel_layouts(monkeypatch, quad):
-    """The tile kernel has two layouts: one workgroup per tile (16-lane groups walk their 4x4 block's queue, two
-    entries per trip) and, for frames of a few hundred tiles, four workgroups per tile (SAS_QUAD: one wave per 4x4
-    block, the four lanes of a DPP quad evaluate four consecutive entries of one pixel).  Left to itself the library
-    picks by tile count, so here each layout is forced onto every kind of frame: a twin fixture with thousands of
-    entries per tile, an image whose size is not a multiple of 16, coplanar splats (a crowded depth bucket: the
-    complete ordering, which under SAS_QUAD quadrant 0 performs alone for the whole tile), long translucent lists
-    (many rounds), the per-quadrant depth maxima behind SAS_DEPTH_FILL_MAX, a launch group, and a frame far past
-    the automatic threshold.  All bit-identical to the oracle."""
+    """A frame has one of two layouts: 16-pixel tiles with one workgroup per tile (16-lane groups walk their 4x4
+    block's queue, two entries per trip) or, for frames of a few hundred tiles, SAS_QUAD: the view is BINNED in 8-pixel
+    tiles, one workgroup per 8x8 quadrant with its own list, one wave per 4x4 block, the four lanes of a DPP quad
+    evaluating four consecutive entries of one pixel (the sigma polynomials still refer to the 16-pixel tile's origin).
+    Left to itself the library picks by tile count, so here each layout is forced onto every kind of frame: a twin
+    fixture with thousands of entries per tile, an image whose size is a multiple of neither 8 nor 16, coplanar splats
+    (a crowded depth bucket: the complete ordering), long translucent lists (many rounds), the per-tile depth maxima
+    behind SAS_DEPTH_FILL_MAX, a launch group, and a frame far past the automatic threshold.  All bit-identical to
+    the oracle; n_isect stays the count of 16-pixel intersections in both, n_keys is what the frame binned."""
     import torch
     from sim_a_splat_amd.rasterizer import Rasterizer
     monkeypatch.setenv("SAS_QUAD", quad)
@@ -702,7 +703,7 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
         ref = oracle.render(means, op, colors, g["viewmat"], g["K"], W, H, background=bg, **kw)
         for k in ("rgb", "alpha", "depth"):
             assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
-        # ragged image, depth fill (per-tile / per-quadrant maxima)
+        # ragged image, depth fill (per-tile maxima)
         sc = make_scene(3000, seed=31, log_scale_mean=float(np.log(0.05)))
         _upload(r, sc)
         _compare(r, sc, ring_camera(75, 53, 70.0), depth_fill=True)
@@ -734,7 +735,9 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
             assert np.array_equal(batch["rgb"][i].cpu().numpy(), ref["rgb"]), i
             assert np.array_equal(batch["depth"][i].cpu().numpy(), ref["depth"]), i
         _compare(r, sc, ring_camera(640, 480, 500.0))
-        assert r.stats()["quad_layout"] == int(quad)
+        st = r.stats()
+        assert st["quad_layout"] == int(quad)
+        assert st["n_keys"] > st["n_isect"] if quad == "1" else st["n_keys"] == st["n_isect"]
     finally:
         r.close()
 
@@ -806,12 +809,11 @@ def test_randomised_edge_cases(rasterizer, seed):
 
 
 def test_quad_layout_crowded_bucket_with_a_wide_depth_range(monkeypatch):
-    """The quad layout's complete-ordering path on a tile whose keys span a WIDE depth range (so that the four
-    workgroups of the tile really do bucket, scan minima / maxima and take the bail decision from the key segment)
-    while one depth bucket is crowded (3 000 coplanar splats): the key segment stays read-only for all four -- quadrant
-    0 orders storage slots in the id segment by the projection's depth words -- so every quadrant takes the same
-    decision and only quadrant 0 writes the tile.  Several frames in flight, twice, so that siblings are dispatched
-    at different times."""
+    """The quad layout's complete-ordering path on tiles whose keys span a WIDE depth range (so that their workgroups
+    really do bucket and scan minima / maxima) while one depth bucket is crowded (3 000 coplanar splats).  Round 2's
+    quad layout shared a 16-pixel tile's list between four workgroups and raced here; since round 3 every 8x8 quadrant
+    is a tile of its own with its own key and id segments, ordered by its one workgroup.  Several frames in flight,
+    twice."""
     import torch
     from sim_a_splat_amd.rasterizer import Rasterizer
     from sim_a_splat_amd.synthetic import SyntheticScene
@@ -901,8 +903,8 @@ def test_tile_kernel_delivers_complete_tile_frames_to_the_host(monkeypatch, quad
     """Frames wanted in pinned host memory whose tiles are all complete (W, H multiples of 16) are stored there by the
     tile kernel itself -- a tile's rows packed in LDS, 16 bytes per lane (8 per lane for a quadrant in the quad
     layout) -- instead of through a device frame and a copy kernel.  Both layouts forced, against the oracle: the Gym
-    camera size (240x320), 640x480, a launch group with per-view pose sets, the complete-ordering path (where in the quad
-    layout quadrant 0 hands out the whole tile and its siblings nothing), an overflowing frame (rendered again), and the
+    camera size (240x320), 640x480, a launch group with per-view pose sets, the complete-ordering path, an overflowing
+    frame (rendered again), and the
     sizes that must NOT take this path (ragged image, pageable destination) beside it."""
     import torch
     from sim_a_splat_amd.rasterizer import Rasterizer

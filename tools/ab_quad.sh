@@ -1,5 +1,5 @@
 #!/bin/bash
-# Quad layout of the tile kernel (SAS_QUAD=1: four workgroups per tile) against the ordinary one (SAS_QUAD=0) on
+# Quad layout of the tile kernel (SAS_QUAD=1: 8-pixel tiles, one workgroup per 8x8 quadrant) against the ordinary one (SAS_QUAD=0) on
 # one GPU box: isolated tile-kernel ms of configs 1-3, the Door-B step, frames/s of configs 2/3.  Run twice.
 for q in 0 1 0 1; do
   export SAS_QUAD=$q
