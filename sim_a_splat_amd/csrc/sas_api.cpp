@@ -331,7 +331,7 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     // The layout is a property of the whole frame: in the quad layout the view is BINNED in 8-pixel tiles (every 8x8
     // quadrant has its own list), so the choice is made here, in front of the projection.
     const int tiles16 = ((a.W + SAS_TILE - 1) / SAS_TILE) * ((a.H + SAS_TILE - 1) / SAS_TILE);
-    sl.quad = use_quad(c, tiles16, a.flags);
+    sl.quad = use_quad(c, tiles16, a.flags) && a.W <= 65535 * (SAS_TILE / 2) && a.H <= 65535 * (SAS_TILE / 2);   // (tile coordinates are 16 bits in info)
     make_cam(a.viewmat, a.K, a.W, a.H, sl.quad ? SAS_TILE / 2 : SAS_TILE, sl.cam);
     const SasCam &cam = sl.cam;
     const int tiles = cam.tw * cam.th;

@@ -7,13 +7,21 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from sim_a_splat_amd import _capi
 from sim_a_splat_amd.rasterizer import Rasterizer
 from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND as BG, config_scene_and_cameras
-for cfg in [int(a) for a in sys.argv[1:]] or [3]:
-    sc, cams = config_scene_and_cameras(cfg)
-    cam = cams[0]
+for cfg in [a if a == "gym" else int(a) for a in sys.argv[1:]] or [3]:
     r = Rasterizer(0)
-    r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
+    if cfg == "gym":   # one 240x320 Gym camera on the 113 831-Gaussian stand-in scene (quad layout: 8-pixel tiles)
+        from sim_a_splat_amd.synthetic import make_scene, ring_camera
+        sc = make_scene(113_831, seed=2, n_groups=8)
+        cam = ring_camera(320, 240, 262.0, yaw_deg=0.0)
+        r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3, group_id=sc.group_id, n_groups=8)
+    else:
+        sc, cams = config_scene_and_cameras(cfg)
+        cam = cams[0]
+        r.upload(sc.means, sc.opacities, sc.sh, quats=sc.quats, scales=sc.scales, sh_degree=3)
     L = _capi.lib()
-    tiles = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    r.render(cam.viewmat, cam.K, cam.width, cam.height, BG, want=("rgb",))
+    px = 8 if r.stats()["quad_layout"] else 16
+    tiles = ((cam.width + px - 1) // px) * ((cam.height + px - 1) // px)
     n = min(tiles, 16384)
     out = (ctypes.c_uint64 * (3 * n))()
     for _ in range(3):
