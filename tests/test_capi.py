@@ -24,6 +24,16 @@ def test_header_symbols_are_exported(built_lib):
         assert hasattr(L, name), name
 
 
+def test_stat_and_stage_names_follow_the_header_enums():
+    """The Python names of sas_frame_stats / sas_stage_times slots are the header's enums, in order."""
+    from sim_a_splat_amd import _capi
+    header = (ROOT / "include" / "sim_a_splat_amd.h").read_text()
+    stats = [n for n in re.findall(r"\bSAS_S_([A-Z_]+)\b", header[header.index("enum { SAS_S_NVISIBLE"):header.index("SAS_S_COUNT")])]
+    assert [n.lower() for n in stats] == [{"n_visible": "nvisible", "n_isect": "nisect", "n_keys": "nkeys"}.get(n, n) for n in _capi.STAT_NAMES]
+    stages = re.findall(r"\bSAS_T_([A-Z]+)\b", header[header.index("enum { SAS_T_PROJECT"):header.index("SAS_T_COUNT")])
+    assert [n.lower() for n in stages] == list(_capi.STAGE_NAMES)
+
+
 def test_version_and_no_device_status(built_lib):
     import torch
     from sim_a_splat_amd import _capi
