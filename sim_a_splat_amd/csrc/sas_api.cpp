@@ -36,6 +36,7 @@ struct RenderArgs {
     float max_depth = 0.0f;
     bool use_max_depth = false;
     hipStream_t stream = nullptr;
+    bool solo = false;         // a blocking call for this one view with nothing else in flight: the caller waits for the frame's chain
     bool valid = false;
 };
 
@@ -112,7 +113,8 @@ struct sas_ctx {
     // quad layout (the frame binned in 8-pixel tiles, one workgroup per 8x8 quadrant): -1 = for views of at most
     // quad_max_tiles 16-pixel tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
     int quad_mode = -1;
-    int quad_max_tiles = 640;
+    int quad_max_tiles = 640;        // views of frames that share the chip (SAS_ASYNC, batches): beyond, the layout's 4 x workgroups lose
+    int quad_max_tiles_solo = 960;   // one blocking view alone on the GPU: its heaviest tile's chain is the frame (tools/quad_threshold.py)
     // sas_render_batch renders the views of a SMALL scene (< kPairMinGaussians: launch-bound frames, the Gym
     // cameras) in groups that share one set of launches (grid.y = view).  SAS_GROUP=1 disables, 2..4 sets the size.
     int group_views = -1;           // -1: half of the slots (two groups can be in flight)
@@ -289,10 +291,10 @@ enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 // flight as well measured worse -- 32 Gym cameras per step in launch groups of two run 30 % faster in the quad
 // layout than in the ordinary one even with four groups in flight (tools/vec_env_probe.py); what loses is a
 // launch that fills the chip by itself (1 200 tiles of 640x480: DESIGN.md 5.21).
-bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags)
+bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags, bool solo)
 {
     if ((flags & SAS_FULL_SORT) || !sas_tiles_lazy_quad_ok((flags & SAS_FAST_EXP) != 0)) return false;
-    return c->quad_mode < 0 ? launch_tiles <= c->quad_max_tiles : c->quad_mode != 0;
+    return c->quad_mode < 0 ? launch_tiles <= (solo ? c->quad_max_tiles_solo : c->quad_max_tiles) : c->quad_mode != 0;
 }
 
 // Can a kernel store to this host address (pinned / registered memory)?  Asked on every call: remembering the
@@ -331,7 +333,7 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     // The layout is a property of the whole frame: in the quad layout the view is BINNED in 8-pixel tiles (every 8x8
     // quadrant has its own list), so the choice is made here, in front of the projection.
     const int tiles16 = ((a.W + SAS_TILE - 1) / SAS_TILE) * ((a.H + SAS_TILE - 1) / SAS_TILE);
-    sl.quad = use_quad(c, tiles16, a.flags) && a.W <= 65535 * (SAS_TILE / 2) && a.H <= 65535 * (SAS_TILE / 2);   // (tile coordinates are 16 bits in info)
+    sl.quad = use_quad(c, tiles16, a.flags, a.solo) && a.W <= 65535 * (SAS_TILE / 2) && a.H <= 65535 * (SAS_TILE / 2);   // (tile coordinates are 16 bits in info)
     make_cam(a.viewmat, a.K, a.W, a.H, sl.quad ? SAS_TILE / 2 : SAS_TILE, sl.cam);
     const SasCam &cam = sl.cam;
     const int tiles = cam.tw * cam.th;
@@ -638,7 +640,7 @@ int sas_create(int device, sas_ctx **out)
     if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SAS_QUAD_TILES")) {
         const int v = atoi(e);
-        if (v >= 0) c->quad_max_tiles = v;
+        if (v >= 0) c->quad_max_tiles = c->quad_max_tiles_solo = v;
     }
     for (Slot &sl : c->slots) {
         ok = ok && hipHostMalloc((void **)&sl.stats_host, 8 * sizeof(unsigned)) == hipSuccess;
@@ -1019,8 +1021,9 @@ static int check_view(sas_ctx *c, const ViewCall &v, int width, int height)
 }
 
 static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, const float *background, unsigned flags,
-                      const float *max_depth, hipStream_t st)
+                      const float *max_depth, hipStream_t st, bool solo)
 {
+    a.solo = solo;
     memcpy(a.viewmat, v.viewmat, sizeof(a.viewmat));
     memcpy(a.K, v.K, sizeof(a.K));
     for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
@@ -1044,7 +1047,7 @@ static void snapshot_poses(sas_ctx *c, Slot &sl, const ViewCall &v)
 // One view (n == 1), a pair of views that share one projection pass (n == 2), or -- `grouped` -- up to
 // SAS_MAX_GROUP views that share every launch (enqueue_group).
 static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int height, const float *background,
-                        unsigned flags, const float *max_depth, void *stream, bool grouped = false)
+                        unsigned flags, const float *max_depth, void *stream, bool grouped = false, bool solo = false)
 {
     if (!c) return SAS_ERR_INVALID;
     for (int k = 0; k < n; ++k) {
@@ -1065,7 +1068,7 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
     Slot *sl[SAS_MAX_GROUP] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < n; ++k) {
         sl[k] = &c->slots[(c->head + c->inflight + k) % c->n_slots];
-        fill_args(sl[k]->args, views[k], width, height, background, flags, max_depth, st);
+        fill_args(sl[k]->args, views[k], width, height, background, flags, max_depth, st, solo && n == 1 && c->inflight == 0);
         snapshot_poses(c, *sl[k], views[k]);
     }
     if (grouped) {
@@ -1100,7 +1103,7 @@ static int render_impl(sas_ctx *c, const float *viewmat, const float *K, int wid
                        uint8_t *mask, const float *max_depth, void *stream)
 {
     const ViewCall v = {viewmat, K, rgb, alpha, depth, rgb8, points, mask};
-    return render_views(c, &v, 1, width, height, background, flags, max_depth, stream);
+    return render_views(c, &v, 1, width, height, background, flags, max_depth, stream, false, !(flags & SAS_ASYNC));
 }
 
 int sas_render(sas_ctx *c, const float *viewmat, const float *K, int width, int height, const float *background,
@@ -1169,7 +1172,7 @@ static int render_batch_impl(sas_ctx *c, int n_views, const float *viewmats, con
         const ViewCall v0 = view(v);
         const int n = (pair && v + 1 < n_views && view(v + 1).poses == v0.poses) ? 2 : 1;
         const ViewCall vc[2] = {v0, view(n == 2 ? v + 1 : v)};
-        int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream);
+        int rc = render_views(c, vc, n, width, height, background, flags | SAS_ASYNC, nullptr, stream, false, n_views == 1 && !(flags & SAS_ASYNC));
         if (rc) return rc;
         v += n;
     }

@@ -744,7 +744,9 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
 
 def test_tile_kernel_layout_follows_the_view_size(rasterizer):
     """Left to itself the library renders views of at most 640 tiles (SAS_QUAD_TILES) in the quad layout and larger
-    ones in the ordinary one; sas_frame_stats reports which."""
+    ones in the ordinary one -- up to 960 tiles when the call is a blocking one for a single view with nothing else in
+    flight (the caller waits for that frame's heaviest tile; frames that share the chip lose with four times the
+    workgroups: tools/quad_threshold.py); sas_frame_stats reports which."""
     import os
     if os.environ.get("SAS_QUAD") is not None or os.environ.get("SAS_QUAD_TILES") is not None:
         pytest.skip("the layout is forced through the environment in this run")
@@ -754,6 +756,15 @@ def test_tile_kernel_layout_follows_the_view_size(rasterizer):
     assert rasterizer.stats()["quad_layout"] == 1
     _compare(rasterizer, sc, ring_camera(640, 480, 520.0))      # 1200 tiles
     assert rasterizer.stats()["quad_layout"] == 0
+    cam = ring_camera(480, 368, 400.0)                          # 690 tiles
+    _compare(rasterizer, sc, cam)                               # ... blocking and alone
+    assert rasterizer.stats()["quad_layout"] == 1
+    ref = oracle.render_scene(sc, cam, background=BG)
+    outs = [rasterizer.render(cam.viewmat, cam.K, 480, 368, BG, want=("rgb",), block=False)["rgb"] for _ in range(3)]   # ... pipelined
+    rasterizer.wait()
+    assert rasterizer.stats()["quad_layout"] == 0
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref["rgb"])
 
 
 @pytest.mark.parametrize("seed", range(12))
