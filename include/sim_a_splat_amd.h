@@ -187,7 +187,9 @@ int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const flo
  * straight into rgb8_host (its rows packed in LDS, 16 B per lane); otherwise the frames are rendered into a
  * staging buffer of the context and copied out on the frames' own streams right behind the tile kernels.  Either
  * way the call returns with the pixels in place and no second round trip (device-to-host copy issued by the
- * caller after the frame) is needed.  Blocking only (SAS_ASYNC is rejected).
+ * caller after the frame) is needed.  Blocking only (SAS_ASYNC is rejected).  Nothing of the caller's on the device is
+ * read or written, so the frames are NOT ordered against work pending on `stream` (two event records and two
+ * stream waits per step that a 120-microsecond Gym step notices: DESIGN.md 5.34).
  */
 int sas_render_batch_host(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                           const float *background, unsigned flags, uint8_t *rgb8_host, void *stream);

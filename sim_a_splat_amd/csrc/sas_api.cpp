@@ -36,6 +36,8 @@ struct RenderArgs {
     float max_depth = 0.0f;
     bool use_max_depth = false;
     hipStream_t stream = nullptr;
+    bool order_caller = true;  // the frame writes device buffers of the caller: it runs behind what the caller's stream holds, and the
+                               // caller's stream is ordered behind it (false: frames delivered to host memory, sas_render_batch_host)
     bool solo = false;         // a blocking call for this one view with nothing else in flight: the caller waits for the frame's chain
     bool valid = false;
 };
@@ -94,6 +96,10 @@ struct sas_ctx {
     // scene
     DevBuf g0, g1, g2, col, perm;
     DevBuf host_stage;   // device staging of sas_render_batch_host's uint8 frames
+    // answer of the pinned-memory query for the host buffer of the sas_render_batch_host call being served (cleared when
+    // the call returns: nothing is remembered across calls)
+    const uint8_t *host_query_base = nullptr, *host_query_end = nullptr;
+    bool host_query_ok = false;
     std::vector<int> perm_host;
     SasScene scene{};
     bool has_scene = false;
@@ -301,7 +307,8 @@ bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags, bool solo)
 // answer per address would be wrong the day a pinned block is freed and a pageable one takes its place.
 bool kernel_can_write_host(sas_ctx *c, const void *p)
 {
-    (void)c;
+    // (within ONE sas_render_batch_host call the views' frames lie in one caller buffer: asked once, see host_query)
+    if (c->host_query_base && p >= c->host_query_base && p < c->host_query_end) return c->host_query_ok;
     hipPointerAttribute_t at{};
     const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
     (void)hipGetLastError();   // a pageable pointer makes the query fail: not an error of ours
@@ -401,7 +408,8 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     // after whatever the caller has enqueued on its stream so far: timed frames as a whole, the others from the
     // tile kernel on (the first thing that writes an output buffer; everything before touches only the scene and
     // the slot's scratch)
-    HIP_TRY(c, hipEventRecord(sl.start, a.stream));
+    const bool order = a.order_caller || timing;
+    if (order) HIP_TRY(c, hipEventRecord(sl.start, a.stream));
     if (timing) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (role != ROLE_FOLLOWER) {
         Slot *mem[1] = {&sl};
@@ -422,7 +430,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
     }
     sas_launch_scatter(st, c->scene, cam.tw, f);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
-    if (!timing) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
+    if (!timing && order) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[4], st));
     const bool fill = a.depth && (a.flags & SAS_DEPTH_FILL_MAX);
@@ -475,10 +483,12 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
         mf.P[k] = sl[k]->params;
     }
     if ((rc = enqueue_poses(c, sl, n, st, true))) return rc;
-    HIP_TRY(c, hipEventRecord(ld.start, a.stream));
+    bool order = false;
+    for (int k = 0; k < n; ++k) order = order || sl[k]->args.order_caller;
+    if (order) HIP_TRY(c, hipEventRecord(ld.start, a.stream));
     sas_launch_project_multi(st, c->scene, mf);
     sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);
-    HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel
+    if (order) HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
     for (int k = 0; k < n; ++k) any_fill = any_fill || (sl[k]->args.depth && (a.flags & SAS_DEPTH_FILL_MAX));
@@ -574,7 +584,9 @@ int complete_oldest(sas_ctx *c)
             // later work on the caller's stream ordered behind the frame (the wait is already satisfied: a
             // no-op on the GPU).  Releasing the caller's stream any earlier would let a stream-ordered
             // consumer read a truncated frame that is about to be rendered again.
-            HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
+            bool order = false;
+            for (int k = 0; k < g; ++k) order = order || mem[k]->args.order_caller;
+            if (order) HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
             for (int k = 0; k < g; ++k) {
                 mem[k]->busy = false;
                 mem[k]->group = 1;
@@ -1024,6 +1036,8 @@ static void fill_args(RenderArgs &a, const ViewCall &v, int width, int height, c
                       const float *max_depth, hipStream_t st, bool solo)
 {
     a.solo = solo;
+    // rgb8 beside rgb8_host is the context's own staging frame (sas_render_batch_host): nothing of the caller's on the device
+    a.order_caller = v.rgb || v.alpha || v.depth || v.points || v.mask || (v.rgb8 && !v.rgb8_host);
     memcpy(a.viewmat, v.viewmat, sizeof(a.viewmat));
     memcpy(a.K, v.K, sizeof(a.K));
     for (int k = 0; k < 3; ++k) a.bg[k] = background ? background[k] : 0.0f;
@@ -1209,10 +1223,23 @@ static int render_batch_host_impl(sas_ctx *c, int n_views, const float *viewmats
         const int rc = complete_all(c);
         if (rc) return rc;
     }
-    const int rc = ensure(c, c->host_stage, 3 * (size_t)width * (size_t)height * (size_t)n_views);
-    if (rc) return rc;
-    return render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, nullptr, nullptr, nullptr,
-                             (uint8_t *)c->host_stage.p, rgb8_host, stream, ps);
+    const size_t bytes = 3 * (size_t)width * (size_t)height * (size_t)n_views;
+    c->host_query_base = nullptr;
+    const bool pinned = kernel_can_write_host(c, rgb8_host);
+    // the staging frames are needed only when the tile kernel cannot deliver the frames itself (prepare_frame's rule)
+    const bool direct = pinned && width % SAS_TILE == 0 && height % SAS_TILE == 0 && ((size_t)rgb8_host & 15) == 0 &&
+                        ((3 * (size_t)width * (size_t)height) & 15) == 0 && !(flags & SAS_FULL_SORT);
+    if (!direct || !c->host_stage.p) {
+        const int rc = ensure(c, c->host_stage, bytes);
+        if (rc) return rc;
+    }
+    c->host_query_base = rgb8_host;
+    c->host_query_end = rgb8_host + bytes;
+    c->host_query_ok = pinned;
+    const int rc = render_batch_impl(c, n_views, viewmats, Ks, width, height, background, flags, nullptr, nullptr, nullptr,
+                                     (uint8_t *)c->host_stage.p, rgb8_host, stream, ps);
+    c->host_query_base = nullptr;
+    return rc;
 }
 
 int sas_render_batch_host(sas_ctx *c, int n_views, const float *viewmats, const float *Ks, int width, int height,
