@@ -580,13 +580,10 @@ int complete_oldest(sas_ctx *c)
             }
         }
         if (!overflow) {
-            // Only now -- the host has seen that the frame did not overflow its intersection buffer -- is
-            // later work on the caller's stream ordered behind the frame (the wait is already satisfied: a
-            // no-op on the GPU).  Releasing the caller's stream any earlier would let a stream-ordered
-            // consumer read a truncated frame that is about to be rendered again.
-            bool order = false;
-            for (int k = 0; k < g; ++k) order = order || mem[k]->args.order_caller;
-            if (order) HIP_TRY(c, hipStreamWaitEvent(sl.args.stream, sl.done, 0));
+            // Only now -- the host has seen the frame finished AND that it did not overflow its intersection buffer -- may
+            // the frame be consumed.  Whatever the caller puts on its stream from here on starts after the frame in real
+            // time: the frame's done event has been waited for by the host (above), so a stream wait on it would be a
+            // no-op on the GPU and one more runtime call and barrier packet per frame (it was issued until round 3).
             for (int k = 0; k < g; ++k) {
                 mem[k]->busy = false;
                 mem[k]->group = 1;
