@@ -23,6 +23,7 @@ if [ "${1:-}" = "--install" ]; then
   cp $src/ramp.txt profiles/${tag}_clock_ramp.txt
   cp $src/timeline_driver_cmd.txt profiles/${tag}_timeline_driver_cmd.txt
   cp $src/env_steps.txt profiles/${tag}_env_steps.txt
+  [ -f $src/api_trace.txt ] && cp $src/api_trace.txt profiles/${tag}_gym_step_api_trace.txt
   [ -f $src/gpu_tests.log ] && cp $src/gpu_tests.log profiles/${tag}_gpu_tests.log
   [ -f $src/bounds_tests.log ] && cp $src/bounds_tests.log profiles/${tag}_bounds_build_gpu_tests.log
   python tools/collect_traffic.py profiles/${tag}_pmc_fetch_size.csv profiles/${tag}_pmc_write_size.csv profiles/hbm_traffic.json > /dev/null
