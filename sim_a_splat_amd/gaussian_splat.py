@@ -72,6 +72,7 @@ class SplatModel:
         self.sh_degree = int(sh_degree)
         self.background_color = torch.tensor(list(background_color), dtype=torch.float32)
         self._raster: Optional[Rasterizer] = None
+        self._bg_src = None
 
     @property
     def num_points(self) -> int:
@@ -105,11 +106,17 @@ class SplatModel:
         K = np.array([[_scalar(camera.fx), 0.0, _scalar(camera.cx)], [0.0, _scalar(camera.fy), _scalar(camera.cy)],
                       [0.0, 0.0, 1.0]], dtype=np.float32)
         W, H = int(_scalar(camera.width)), int(_scalar(camera.height))
+        return self.render_view(V, K, W, H)
+
+    def render_view(self, V: np.ndarray, K: np.ndarray, W: int, H: int) -> Dict[str, torch.Tensor]:
+        """The outputs of ``get_outputs_for_camera`` from a world-to-camera matrix and intrinsics (what ``GaussianSplat.render``
+        calls: the camera objects of the reference cost more host time per call than a 640x480 frame takes to render)."""
         bg = self.background_color
         r = self._rasterizer()
-        out = r.render(V, K, W, H, bg.tolist(), want=("rgb", "alpha", "depth"), depth_fill_max=True)
-        return {"rgb": out["rgb"], "depth": out["depth"], "accumulation": out["alpha"],
-                "background": bg.to(r.device).expand(H, W, 3)}
+        if self._bg_src is not bg:                     # (re)assigned background: its list and device copy, once
+            self._bg_src, self._bg_list, self._bg_dev = bg, [float(v) for v in bg.reshape(-1)], bg.to(r.device)
+        out = r.render(V, K, W, H, self._bg_list, want=("rgb", "alpha", "depth"), depth_fill_max=True)
+        return {"rgb": out["rgb"], "depth": out["depth"], "accumulation": out["alpha"], "background": self._bg_dev.expand(H, W, 3)}
 
 
 class _Dataset:
@@ -181,6 +188,7 @@ class GaussianSplat:
 
     def get_cameras(self):
         self.cameras = self.dataset.cameras
+        self._cam0 = None
         if self.res_factor is not None:
             self.cameras.rescale_output_resolution(self.res_factor)
 
@@ -193,18 +201,36 @@ class GaussianSplat:
         H = int(self.cameras[0].height.item())
         return H, W, K
 
+    def _camera0(self):
+        """(stamp, K float32 [3,3], W, H) of camera 0, cached until the cameras change."""
+        k, cams = self._cam0, self.cameras
+        stamp = (cams, cams.fx, getattr(cams.fx, "_version", 0), cams.width)   # rescale_output_resolution replaces the tensors
+        if k is None or k[0][0] is not cams or k[0][1] is not stamp[1] or k[0][2] != stamp[2] or k[0][3] is not stamp[3]:
+            c0 = cams[0]
+            K = np.array([[_scalar(c0.fx), 0.0, _scalar(c0.cx)], [0.0, _scalar(c0.fy), _scalar(c0.cy)], [0.0, 0.0, 1.0]], dtype=np.float32)
+            k = self._cam0 = (stamp, K, int(_scalar(c0.width)), int(_scalar(c0.height)))
+        return k
+
     # -- :123-177 ------------------------------------------------------------------------------------------
     def render(self, pose, compute_semantics: Optional[bool] = False, debug_mode: bool = False) -> Dict[str, torch.Tensor]:
         """``pose``: [>=3,4] camera-to-world, OpenGL axes, nerfstudio scene frame."""
         from . import ns_run
-        camera_to_world = torch.as_tensor(pose, dtype=torch.float32)[None, :3, ...]
-        c0 = self.cameras[0]
-        cameras = ns_run.Cameras(camera_to_world, c0.fx, c0.fy, c0.cx, c0.cy, c0.width, c0.height)
+        model = self.pipeline.model
         tnow = time.perf_counter()
-        try:
-            outputs = self.pipeline.model.get_outputs_for_camera(cameras, obb_box=None, compute_semantics=compute_semantics)
-        except TypeError:
-            outputs = self.pipeline.model.get_outputs_for_camera(cameras, obb_box=None)
+        if isinstance(model, SplatModel) and not compute_semantics:
+            # the reference builds a one-camera Cameras object per call from camera 0's intrinsics (:127-136); the same
+            # numbers without the dozen small tensor operations (70 of a 200-microsecond call at 640x480)
+            k = self._camera0()
+            c2w = pose[:3] if isinstance(pose, (np.ndarray, torch.Tensor)) else np.asarray(pose, dtype=np.float32)[:3]
+            outputs = model.render_view(viewmat_from_c2w_opengl(c2w), k[1], k[2], k[3])
+        else:
+            camera_to_world = torch.as_tensor(pose, dtype=torch.float32)[None, :3, ...]
+            c0 = self.cameras[0]
+            cameras = ns_run.Cameras(camera_to_world, c0.fx, c0.fy, c0.cx, c0.cy, c0.width, c0.height)
+            try:
+                outputs = model.get_outputs_for_camera(cameras, obb_box=None, compute_semantics=compute_semantics)
+            except TypeError:
+                outputs = model.get_outputs_for_camera(cameras, obb_box=None)
         if debug_mode:
             torch.cuda.synchronize(outputs["rgb"].device)
             print("Rendering time: ", time.perf_counter() - tnow)
