@@ -905,17 +905,20 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                     const float sg = fma_(H.y, pc.xy, fma_(H.x, pc.yy, fma_(K.w, pc.xx, fma_(K.z, pc.y, fma_(K.y, p.x, K.x)))));
                     const float E = FAST_EXP ? __expf(fmaxf(-sg, -86.0f)) : c_expf_neg(fmaxf(-sg, -86.0f), sE5);
                     const float al = fminf(kMaxAlpha, H.w * E);
-                    // alpha of entries k .. k + 3 for this lane's pixel
-                    const float a0 = quad_bcast<0>(al), a1 = quad_bcast<1>(al), a2 = quad_bcast<2>(al), a3 = quad_bcast<3>(al);
+                    // A skipped splat weighs 0: decided HERE, once per lane for its own entry, so that the chain below is one
+                    // multiply (its operand the quad broadcast of entry j's alpha: v_mul_f32_dpp) and one subtraction per
+                    // entry instead of broadcast + compare + multiply + select (0 * T == +0 for the finite T of the path:
+                    // the same bits as the select's 0).
+                    const float alz = (al < kAlphaThr) ? 0.0f : al;
                     // as if no pixel terminated: T only falls, one test of the last T tells
                     const float T0 = p.T;
-                    const float w0 = (a0 < kAlphaThr) ? 0.0f : a0 * T0;
+                    const float w0 = quad_bcast<0>(alz) * T0;
                     const float T1 = T0 - w0;
-                    const float w1 = (a1 < kAlphaThr) ? 0.0f : a1 * T1;
+                    const float w1 = quad_bcast<1>(alz) * T1;
                     const float T2 = T1 - w1;
-                    const float w2 = (a2 < kAlphaThr) ? 0.0f : a2 * T2;
+                    const float w2 = quad_bcast<2>(alz) * T2;
                     const float T3 = T2 - w2;
-                    const float w3 = (a3 < kAlphaThr) ? 0.0f : a3 * T3;
+                    const float w3 = quad_bcast<3>(alz) * T3;
                     const float T4 = T3 - w3;
                     float v0 = w0, v1 = w1, v2 = w2, v3 = w3, Tn = T4;
                     bool all_dead = false;
