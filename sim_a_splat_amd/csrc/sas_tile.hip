@@ -521,10 +521,22 @@ DEV float vgpr_const(unsigned bits)
 // by launch index (tools/wg_time.py).  Plain stores: same-address atomics would dominate the kernel.
 constexpr int kDbgWgMax = 16384;
 __device__ unsigned long long g_dbg_wg[3 * kDbgWgMax];
+// ... and where the time went (ticks, thread 0's view): [0] ordering the chunks, [1] compositing (staging, masks, queues, trips),
+// [2] the trips alone, [3] batches
+__device__ unsigned long long g_dbg_ph[4 * kDbgWgMax];
 extern "C" int sas_debug_wg(unsigned long long *out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_wg), sizeof(unsigned long long) * 3 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
 }
+extern "C" int sas_debug_wg_phases(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ph), sizeof(unsigned long long) * 4 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
+}
+#define PH_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) g_dbg_ph[4 * blockIdx.x + (i)] += (v); } while (0)
+#define PH_T() wall_clock64()
+#else
+#define PH_ADD(i, v) do { } while (0)
+#define PH_T() 0ull
 #endif
 #ifdef SAS_TUNE_STATS
 // A/B builds only: [0] wave-iterations of the compositing loop, [1] trips on which a pixel terminated,
@@ -891,7 +903,13 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                 if (has && SAS_IN(qn + below, 256, 232)) wq[qn + below] = (unsigned short)(lane16 + 1024u * j);
                 qn += (int)__popcll(m);
             }
+#if defined(SAS_TUNE_ABLATE) && (SAS_TUNE_ABLATE & 4)
+            const int kend = 0;   // timing experiment: staging, masks and queues, but no trips (wrong images)
+#else
             const int kend = __builtin_amdgcn_readfirstlane(qn);
+#endif
+            PH_ADD(3, 1);
+            const unsigned long long t_t = PH_T();
             if (kend > 0) {
                 int k = 0;
                 unsigned off = wq[e];
@@ -952,6 +970,7 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                     if (all_dead) k = kend;
                 } while (k < kend);
             }
+            PH_ADD(2, PH_T() - t_t);
             wdone = __all(pix_dead(p));
         }
     }
@@ -1146,6 +1165,8 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
 
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax)
+        for (int k = 0; k < 4; ++k) g_dbg_ph[4 * blockIdx.x + k] = 0ull;
 #endif
     // QUAD: the frame is binned in 8-pixel tiles (c.tile_px == 8): this workgroup's tile is the 8x8 quadrant qd of the
     // contract's 16-pixel tile (tx, ty), whose origin the sigma polynomials refer to (pixel_of_quad); the list is its own
@@ -1171,8 +1192,12 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     bool wdone = __all(!inside);
     // composite `count` ordered entries in this kernel's layout
     auto blend = [&](int count, auto slot_at) -> bool {
-        if constexpr (QUAD) return blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone);
-        else return blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone);
+        const unsigned long long t_b = PH_T();
+        bool r;
+        if constexpr (QUAD) r = blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone);
+        else r = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone);
+        PH_ADD(1, PH_T() - t_b);
+        return r;
     };
 
     const long long beg = f.tile_offset[tile];
@@ -1246,8 +1271,10 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             }
             __syncthreads();
             if (!(ablate & 1)) {
+                const unsigned long long t_s = PH_T();
                 if (!big) lds_bucket_rank_sort<NK>(ck, n, 0, shift, s_hist, s_cur, perm);
                 else lds_radix_sort<4, NK>(ck, n, span, perm, cnt, dbase, s_wsum);
+                PH_ADD(0, PH_T() - t_s);
             }
         }
 #endif
@@ -1391,6 +1418,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             __syncthreads();
             const int m = (int)s_m;
             // ---- order the chunk, then composite it
+            const unsigned long long t_s = PH_T();
             if (!(ablate & 1)) {
                 if (!big) {
                     lds_bucket_rank_sort<CH / kLazyThreads>(ck, m, b0, shift, s_hist, s_cur, perm);
@@ -1400,6 +1428,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                     lds_radix_sort<4, CH / kLazyThreads>(ck, m, rel_span, perm, cnt, dbase, s_wsum);
                 }
             }
+            PH_ADD(0, PH_T() - t_s);
             bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
                 all_done = blend(m, [&](int i) { return (long long)lo32(ck[i]); });
