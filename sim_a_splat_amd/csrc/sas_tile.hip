@@ -1282,6 +1282,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     } else if (n > CH) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
         constexpr int U = SAS_TUNE_U;
+        const unsigned long long t_p = PH_T();
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         s_hist[tid] = 0u;
         __syncthreads();
@@ -1317,6 +1318,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         }
         __syncthreads();
         int b_next = 0;
+        if (!QUAD) PH_ADD(2, PH_T() - t_p);   // (ordinary layout: [2] = the passes over the keys, [3] = of which the rounds' collect passes)
         bool bail = false;
         bool partitioned = false;                 // the keys left after the first round have been laid out by bucket
         int p_consumed = 0;                       // ... and this many of them have been composited since
@@ -1385,6 +1387,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 s_cur[tid] = my_incl;   // END of bucket t inside the chunk (what the collect pass leaves): b0 is the first non-empty bucket of the scan
             }
             const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
+            const unsigned long long t_c = PH_T();
             if (!partitioned) {
                 for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
                     unsigned long long kk[U];
@@ -1416,6 +1419,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 }
             }
             __syncthreads();
+            if (!QUAD) { PH_ADD(2, PH_T() - t_c); PH_ADD(3, PH_T() - t_c); }
             const int m = (int)s_m;
             // ---- order the chunk, then composite it
             const unsigned long long t_s = PH_T();

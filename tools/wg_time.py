@@ -43,13 +43,15 @@ for cfg in [a if a == "gym" else int(a) for a in sys.argv[1:]] or [3]:
     for i in np.argsort(-d)[:5]:
         extra = ""
         if ph is not None:   # thread 0's clock: ordering, compositing (of which the trips), batches
-            trips = f" (wave 0's trips {ph[i, 2] * 0.01:5.1f}) us in {ph[i, 3]} batches" if ph[:, 3].any() else " us"   # (the quad layout's loop is instrumented)
+            trips = f" (wave 0's trips {ph[i, 2] * 0.01:5.1f}) us in {ph[i, 3]} batches" if r.stats()["quad_layout"] else " us"   # (the quad layout's loop is instrumented)
             extra = f"; ordering {ph[i, 0] * 0.01:5.1f}, compositing {ph[i, 1] * 0.01:5.1f}{trips}"
         print(f"  long: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us{extra}")
     if ph is not None:
         tot = d.sum()
+        if not r.stats()["quad_layout"]:
+            print(f"  long lists (ordinary layout): passes over the keys {ph[:, 2].sum() * 0.01 / tot:.2f} of the slot time, of which the rounds' collect passes {ph[:, 3].sum() * 0.01 / tot:.2f}")
         print(f"  all workgroups: ordering {ph[:, 0].sum() * 0.01 / tot:.2f}, compositing (staging, masks, queues, trips, waits for the slowest wave) "
-              f"{ph[:, 1].sum() * 0.01 / tot:.2f} of the slot time" + (f", wave 0's trips {ph[:, 2].sum() * 0.01 / tot:.2f}" if ph[:, 3].any() else ""))
+              f"{ph[:, 1].sum() * 0.01 / tot:.2f} of the slot time" + (f", wave 0's trips {ph[:, 2].sum() * 0.01 / tot:.2f}" if r.stats()["quad_layout"] else ""))
     for i in np.argsort(-e)[:3]:
         print(f"  last: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us")
     for q in (0.25, 0.5, 0.75, 0.9):
