@@ -535,7 +535,7 @@ extern "C" int sas_debug_wg_phases(unsigned long long *out, int n)
 #define PH_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) g_dbg_ph[4 * blockIdx.x + (i)] += (v); } while (0)
 #define PH_T() wall_clock64()
 #else
-#define PH_ADD(i, v) do { } while (0)
+#define PH_ADD(i, v) do { (void)(v); } while (0)
 #define PH_T() 0ull
 #endif
 #ifdef SAS_TUNE_STATS
