@@ -197,6 +197,10 @@ class SplatHandler:
         if cam_poses is None:
             cam_poses = [(chs.camera.wxyz, chs.camera.position)]
         cam = [poses.pose_wxyz_xyz(p) for p in cam_poses]
+        n = len(cam)
+        s0 = render_size[0] if n else None
+        if n and hasattr(chs, "get_renders") and all(s[0] == s0[0] and s[1] == s0[1] for s in render_size[1:n]):
+            return list(chs.get_renders(int(s0[0]), int(s0[1]), cam))      # the usual rig: every camera the same size, one batch
         sizes = [(int(s[0]), int(s[1])) for s in render_size]
         out: List[Optional[np.ndarray]] = [None] * len(cam)
         for hw in dict.fromkeys(sizes[:len(cam)]):
