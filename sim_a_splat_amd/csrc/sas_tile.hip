@@ -523,16 +523,16 @@ constexpr int kDbgWgMax = 16384;
 __device__ unsigned long long g_dbg_wg[3 * kDbgWgMax];
 // ... and where the time went (ticks, thread 0's view): [0] ordering the chunks, [1] compositing (staging, masks, queues, trips),
 // [2] the trips alone, [3] batches
-__device__ unsigned long long g_dbg_ph[4 * kDbgWgMax];
+__device__ unsigned long long g_dbg_ph[8 * kDbgWgMax];   // [4..7] quad layout, per batch: first barrier, mask + staging, second barrier, queue building
 extern "C" int sas_debug_wg(unsigned long long *out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_wg), sizeof(unsigned long long) * 3 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
 }
 extern "C" int sas_debug_wg_phases(unsigned long long *out, int n)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ph), sizeof(unsigned long long) * 4 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ph), sizeof(unsigned long long) * 8 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
 }
-#define PH_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) g_dbg_ph[4 * blockIdx.x + (i)] += (v); } while (0)
+#define PH_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) g_dbg_ph[8 * blockIdx.x + (i)] += (v); } while (0)
 #define PH_T() wall_clock64()
 #else
 #define PH_ADD(i, v) do { (void)(v); } while (0)
@@ -841,6 +841,9 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
         have = idx < count;
         if (have) {
             long long id = slot_at(idx);
+#if defined(SAS_TUNE_ABLATE) && (SAS_TUNE_ABLATE & 8)
+            id &= 1023;   // timing experiment: the records come from 48 KiB that stay in the caches (wrong images)
+#endif
             if (!SAS_IN(id, n_gauss, 231) || id >= n_gauss) id = n_gauss - 1;
             ra = f.rec[3 * id + 0];
             rb = f.rec[3 * id + 1];
@@ -862,8 +865,11 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
     const char *q2b = reinterpret_cast<const char *>(L.q2);
     bool all_done = false;
     for (int at = 0; at < count; at += 256) {
+        const unsigned long long t_b0 = PH_T();
         const bool every_done = __syncthreads_and(wdone);
         if (every_done) { all_done = true; break; }
+        const unsigned long long t_b1 = PH_T();
+        PH_ADD(4, t_b1 - t_b0);
         unsigned ment = 0u;
         if (have) ment = block_mask4(tx, ty, qd, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
         {
@@ -885,7 +891,11 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
             z[0] = make_uint2(sw, sw);
             if (lane < 2) z[64] = make_uint2(sw, sw);
         }
+        const unsigned long long t_b2 = PH_T();
+        PH_ADD(5, t_b2 - t_b1);
         __syncthreads();
+        const unsigned long long t_b3 = PH_T();
+        PH_ADD(6, t_b3 - t_b2);
         if (at + 256 < count) fetch(at + 256);
         if (!wdone) {
             const int cnt = (count - at) < 256 ? (count - at) : 256;
@@ -910,6 +920,7 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
 #endif
             PH_ADD(3, 1);
             const unsigned long long t_t = PH_T();
+            PH_ADD(7, t_t - t_b3);
             if (kend > 0) {
                 int k = 0;
                 unsigned off = wq[e];
@@ -1166,7 +1177,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
 #ifdef SAS_TUNE_WGTIME
     const unsigned long long t_wg0 = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax)
-        for (int k = 0; k < 4; ++k) g_dbg_ph[4 * blockIdx.x + k] = 0ull;
+        for (int k = 0; k < 8; ++k) g_dbg_ph[8 * blockIdx.x + k] = 0ull;
 #endif
     // QUAD: the frame is binned in 8-pixel tiles (c.tile_px == 8): this workgroup's tile is the 8x8 quadrant qd of the
     // contract's 16-pixel tile (tx, ty), whose origin the sigma polynomials refer to (pixel_of_quad); the list is its own

@@ -37,13 +37,15 @@ for cfg in [a if a == "gym" else int(a) for a in sys.argv[1:]] or [3]:
           f"sum of durations {d.sum() / 1e3:.1f} ms -> mean residency {d.sum() / e.max():.0f} workgroups")
     ph = None
     if hasattr(L, "sas_debug_wg_phases"):
-        o4 = (ctypes.c_uint64 * (4 * n))()
+        o4 = (ctypes.c_uint64 * (8 * n))()
         L.sas_debug_wg_phases(o4, n)
-        ph = np.array(o4, dtype=np.uint64).reshape(n, 4).astype(np.int64)
+        ph = np.array(o4, dtype=np.uint64).reshape(n, 8).astype(np.int64)
     for i in np.argsort(-d)[:5]:
         extra = ""
         if ph is not None:   # thread 0's clock: ordering, compositing (of which the trips), batches
             trips = f" (wave 0's trips {ph[i, 2] * 0.01:5.1f}) us in {ph[i, 3]} batches" if r.stats()["quad_layout"] else " us"   # (the quad layout's loop is instrumented)
+            if r.stats()["quad_layout"]:
+                trips += f"; per batch: first barrier {ph[i, 4] * 0.01:4.1f}, mask + staging (waits for the gathered records) {ph[i, 5] * 0.01:4.1f}, second barrier {ph[i, 6] * 0.01:4.1f}, queue {ph[i, 7] * 0.01:4.1f} us in all"
             extra = f"; ordering {ph[i, 0] * 0.01:5.1f}, compositing {ph[i, 1] * 0.01:5.1f}{trips}"
         print(f"  long: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us{extra}")
     if ph is not None:
