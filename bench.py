@@ -137,6 +137,15 @@ def workload(cfg, rank, world, views_per_step, n_gaussians):
     return scene, cams, ("rgb", "rgb8"), None, desc, "strong", len(all_cams)
 
 
+def cameras_of(cfg, rank, world, views_per_step):
+    """The cameras rank `rank` renders per step (workload()'s second result, without the scene)."""
+    if cfg == 3:
+        return [ring_camera(1920, 1080, 1000.0, yaw_deg=45.0 * rank + 180.0 * v) for v in range(views_per_step)]
+    from sim_a_splat_amd.synthetic import config_cameras
+    all_cams = config_cameras(cfg)
+    return [all_cams[v] for v in sdist.shard_views(len(all_cams), rank, world)]
+
+
 def self_launch(n, argv, dry_run):
     """`bench.py --gpus N` without a launcher: N ranks through torch.distributed.run, as the driver starts them.
     Returns the child's exit code; its stdout (rank 0's JSON line) is passed through."""
@@ -256,8 +265,16 @@ def main():
         else:
             idle_steps[0] += 1
 
+    # what rank 0 received for the LAST step of a timed run, checked against its own renders of every rank's views after
+    # the timing (the scene is replicated: rank 0 can render any view)
+    keep = {"on": False, "step": None, "frames": None}
+
+    def on_gathered(step, frames):
+        if rank == 0 and keep["on"] and frames is not None and step == a.steps - 1:
+            keep["step"], keep["frames"] = step, [f.clone() for f in frames]
+
     pipe = sdist.StepPipeline(world, rank, bufs, submit, lambda: (r.frames_completed()[1] // V) if V else idle_steps[0], r.wait,
-                              payload=lambda b: b["rgb8"])
+                              payload=lambda b: b["rgb8"], on_gathered=on_gathered)
 
     def run(steps, time_every):
         pipe.begin()
@@ -274,9 +291,11 @@ def main():
     def timed_pass():
         run(a.warmup, 1)
         r.stage_time_means(reset=True)
+        keep["on"] = True
         t0 = time.perf_counter()
         run(a.steps, a.time_every)
         dt = time.perf_counter() - t0
+        keep["on"] = False
         means, frames = r.stage_time_means(reset=True)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -293,6 +312,20 @@ def main():
         pass_times.append(elapsed)
         if abs(pass_times[-1] - pass_times[-2]) <= 0.01 * pass_times[-2]:
             break
+
+    gather_check = None
+    if rank == 0 and world > 1 and keep["frames"] is not None:
+        # every rank's frames of that step, as they arrived, against rank 0's own blocking renders of the same views
+        if step_poses is not None:
+            r.set_group_poses(step_poses[keep["step"] % len(step_poses)])
+        n_cmp, equal = 0, True
+        for src in range(world):
+            for k, c_ in enumerate(cameras_of(a.config, src, world, a.views_per_step)):
+                own = r.render(c_.viewmat, c_.K, W, H, BG, want=("rgb8",))["rgb8"]
+                equal = equal and bool(torch.equal(own.cpu(), keep["frames"][src][k].cpu()))
+                n_cmp += 1
+        gather_check = {"step": keep["step"], "frames_compared": n_cmp, "bit_equal_to_rank0_renders": equal}
+        keep["frames"] = None
 
     line = None
     if rank == 0:
@@ -334,7 +367,8 @@ def main():
                            "what": "the same W warm-up + K timed steps started on the idle GPU (first ~25 ms: clock ramp)"},
             "config": {"workload": desc, "n_gaussians": scene.n, "n_visible": st["n_visible"], "n_intersections": st["n_isect"],
                        "views_per_step": views_all, "parallelism": f"views{world}x{V}",
-                       "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none"},
+                       "gather": "uint8 frames to rank 0 (RCCL), each step as soon as its frames are complete" if world > 1 else "none",
+                       "gather_check": gather_check},
             "roofline": {"bound": "hbm", "kernel": "k_tile_lazy", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_tile_lazy") if a.config == 3 else None,
                          "frac_is": "co-resident: the launch duration inside the timed region, where `tile_kernels_in_flight` launches of this "

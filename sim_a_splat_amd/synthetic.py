@@ -130,25 +130,32 @@ def ring_camera(width: int, height: int, f: float, yaw_deg: float = 0.0, radius:
 
 # ---- the five BASELINE.json configs -------------------------------------------------------
 
+def config_cameras(cfg: int) -> list:
+    """Camera list of BASELINE config ``cfg`` (1..5)."""
+    if cfg == 1:
+        return [ring_camera(256, 256, 256.0)]
+    if cfg == 2:
+        return [ring_camera(640, 480, 525.0)]
+    if cfg == 3:
+        return [ring_camera(1920, 1080, 1000.0)]
+    if cfg == 4:
+        return [ring_camera(640, 480, 525.0, yaw_deg=45.0 * k) for k in range(8)]
+    if cfg == 5:
+        return [ring_camera(1920, 1080, 1000.0, yaw_deg=90.0 * k) for k in range(4)]
+    raise ValueError(f"unknown BASELINE config {cfg}")
+
+
 def config_scene_and_cameras(cfg: int, scale: float = 1.0) -> Tuple[SyntheticScene, list]:
     """Scene + camera list of BASELINE config ``cfg`` (1..5).  ``scale`` < 1 shrinks N for tests."""
+    cams = config_cameras(cfg)
     if cfg == 1:
         sc = make_scene(max(1, int(10_000 * scale)), seed=1)
-        cams = [ring_camera(256, 256, 256.0)]
-    elif cfg == 2:
+    elif cfg in (2, 4):
         sc = make_scene(max(1, int(292_247 * scale)), seed=2, n_groups=7)
-        cams = [ring_camera(640, 480, 525.0)]
     elif cfg == 3:
         sc = make_scene(max(1, int(1_000_000 * scale)), seed=3, log_scale_mean=float(np.log(0.006)))
-        cams = [ring_camera(1920, 1080, 1000.0)]
-    elif cfg == 4:
-        sc = make_scene(max(1, int(292_247 * scale)), seed=2, n_groups=7)
-        cams = [ring_camera(640, 480, 525.0, yaw_deg=45.0 * k) for k in range(8)]
-    elif cfg == 5:
-        sc = make_scene(max(1, int(5_000_000 * scale)), seed=5, log_scale_mean=float(np.log(0.006)))
-        cams = [ring_camera(1920, 1080, 1000.0, yaw_deg=90.0 * k) for k in range(4)]
     else:
-        raise ValueError(f"unknown BASELINE config {cfg}")
+        sc = make_scene(max(1, int(5_000_000 * scale)), seed=5, log_scale_mean=float(np.log(0.006)))
     sc.meta["config"] = cfg
     return sc, cams
 
