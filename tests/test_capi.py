@@ -68,3 +68,22 @@ def test_rasterizer_fails_loudly_without_gpu():
     from sim_a_splat_amd._capi import SasError
     with pytest.raises(SasError):
         Rasterizer(0)
+
+
+def test_no_tracked_file_is_a_binary_object():
+    """History stays source-only: no ELF / code-object / archive among the tracked files (built .so files travel
+    to the GPU box untracked).  .npz fixtures are zip archives of arrays: data, allowed."""
+    import subprocess
+    res = subprocess.run(["git", "ls-files", "-z"], cwd=ROOT, capture_output=True)
+    if res.returncode != 0:
+        pytest.skip("not a git checkout (the GPU box receives a snapshot without .git)")
+    bad = []
+    for rel in filter(None, res.stdout.decode().split("\0")):
+        p = ROOT / rel
+        if not p.is_file():
+            continue
+        with open(p, "rb") as f:
+            magic = f.read(8)
+        if magic[:4] == b"\x7fELF" or magic[:7] == b"!<arch>" or magic[:8] == b"__CLANG_" or ".hipv4-" in rel or ".host-x86" in rel:
+            bad.append(rel)
+    assert not bad, bad
