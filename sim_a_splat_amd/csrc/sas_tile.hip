@@ -534,9 +534,20 @@ extern "C" int sas_debug_wg_phases(unsigned long long *out, int n)
 }
 #define PH_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) g_dbg_ph[8 * blockIdx.x + (i)] += (v); } while (0)
 #define PH_T() wall_clock64()
+// ... and an EXCLUSIVE partition of thread 0's wall time (ordinary layout): PH_LAP(i) books the ticks since the previous lap on slot i.
+// [0] tile order + offsets, [1] min / max pass, [2] histogram pass, [3] bucket selection, [4] partition, [5] collect, [6] ordering a chunk,
+// [7] first batch of a chunk: records + barrier, [8] staging + masks + barrier, [9] queue building, [10] trips, [11] batch barrier (other waves),
+// [12] epilogue, [13] short list: loads + ordering
+__device__ unsigned long long g_dbg_lap[16 * kDbgWgMax];
+extern "C" int sas_debug_wg_laps(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_lap), sizeof(unsigned long long) * 16 * (size_t)(n < kDbgWgMax ? n : kDbgWgMax)) == hipSuccess ? 0 : -1;
+}
+#define PH_LAP(i) do { if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax) { const unsigned long long now_ = wall_clock64(); g_dbg_lap[16 * blockIdx.x + (i)] += now_ - ph_lap_; ph_lap_ = now_; } } while (0)
 #else
 #define PH_ADD(i, v) do { (void)(v); } while (0)
 #define PH_T() 0ull
+#define PH_LAP(i) do { } while (0)
 #endif
 #ifdef SAS_TUNE_STATS
 // A/B builds only: [0] wave-iterations of the compositing loop, [1] trips on which a pixel terminated,
@@ -590,7 +601,7 @@ DEV BlendLds blend_lds(unsigned char *raw)
 // the workgroup).  `slot_at(i)` gives the storage slot of entry i.
 template <bool FAST_EXP, typename SlotAt>
 DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const PixConst pc, int count, SlotAt slot_at,
-                     const BlendLds &L, PixState &p, bool &wdone)
+                     const BlendLds &L, PixState &p, bool &wdone, unsigned long long &ph_lap_)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
@@ -632,6 +643,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     for (int at = 0; at < count; at += 256) {
         // the previous batch is fully consumed; leave once every wave has terminated
         const bool every_done = __syncthreads_and(wdone);
+        PH_LAP(11);
 #ifdef SAS_TUNE_STATS
         if (t_loop_end) DBG_ADD(6, clock64() - t_loop_end);   // [6] cycles waves waited for the slowest wave of a batch
 #endif
@@ -668,6 +680,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             z[1] = make_uint4(sw, sw, sw, sw);
         }
         __syncthreads();
+        PH_LAP(at == 0 ? 7 : 8);   // (the first batch's records were requested just before: their latency is in this lap)
         if (at + 256 < count) fetch(at + 256);   // next batch in flight while this one is blended
         if (!wdone) {
             const int cnt = (count - at) < 256 ? (count - at) : 256;
@@ -700,6 +713,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                     if (((dm >> (16 * g)) & 0xffffull) == 0xffffull) qn[g] = 0;
             }
             const int kmax = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
+            PH_LAP(9);
 #ifdef SAS_TUNE_STATS
             const long long t_loop = clock64();
 #endif
@@ -806,6 +820,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 } while (k < kend);
             }
             wdone = __all(pix_dead(p));
+            PH_LAP(10);
 #ifdef SAS_TUNE_STATS
             t_loop_end = clock64();
             DBG_ADD(7, t_loop_end - t_loop);   // [7] cycles in the compositing loop
@@ -1084,8 +1099,9 @@ __global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long lon
         long long end = f.tile_offset[tile + 1];
         if (end > f.cap) end = f.cap;
         const int *ids = f.sorted_ids + beg;
+        unsigned long long ph_lap_ = 0ull;
         blend_range<FAST_EXP>(f, n_gauss, tx, ty, pix_const(ox, oy), (int)(end - beg),
-                              [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone);
+                              [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone, ph_lap_);
         unsigned packed;
         const float ED = write_pixel(o, p, inside, ix, iy, c.W, packed);
         if (o.rgb8_host) store_rows_to_host<16>(o.rgb8_host, c.W, tx * SAS_TILE, ty * SAS_TILE, ox, oy, true, packed, s_raw);
@@ -1201,12 +1217,19 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     const int out_side = QUAD ? 8 : 16;       // what this workgroup hands out: its quadrant or the whole tile
     PixState p = pix_init(inside, ox);
     bool wdone = __all(!inside);
+#ifdef SAS_TUNE_WGTIME
+    unsigned long long ph_lap_ = t_wg0;
+    if (threadIdx.x == 0 && blockIdx.x < kDbgWgMax)
+        for (int k = 0; k < 16; ++k) g_dbg_lap[16 * blockIdx.x + k] = 0ull;
+#else
+    unsigned long long ph_lap_ = 0ull;
+#endif
     // composite `count` ordered entries in this kernel's layout
     auto blend = [&](int count, auto slot_at) -> bool {
         const unsigned long long t_b = PH_T();
         bool r;
         if constexpr (QUAD) r = blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone);
-        else r = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone);
+        else r = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone, ph_lap_);
         PH_ADD(1, PH_T() - t_b);
         return r;
     };
@@ -1216,6 +1239,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     if (end > f.cap) end = f.cap;
     const int n = (int)(end - beg);
     const unsigned long long *g = f.keys + beg;
+    if (n >= 0) PH_LAP(0);   // (n: the dependent loads of the tile's index and its offsets have returned)
     // the tile kernel's waves issue ahead of the co-resident binning waves of the next frames (+1.2 % frames/s at config 3:
     // what a step costs is the tile kernel's slot time; the reverse priority costs 0.5 %)
     __builtin_amdgcn_s_setprio(3);
@@ -1289,6 +1313,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             }
         }
 #endif
+        PH_LAP(13);
         if (!(ablate & 2)) blend(n, [&](int i) { return (long long)lo32(ck[i]); });
     } else if (n > CH) {
         // ---- long list: every pass over the keys keeps U independent loads per thread in flight
@@ -1313,6 +1338,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
+        PH_LAP(1);
         const unsigned dmin = s_mn, span = s_mx - s_mn;
         const int sbits = span ? 32 - __clz(span) : 0;
         const int shift = sbits > 8 ? sbits - 8 : 0;   // 256 depth buckets over the tile's range
@@ -1328,6 +1354,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 if (i0 + u * kLazyThreads + tid < n && SAS_IN((dd[u] - dmin) >> shift, 256, 208)) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
         }
         __syncthreads();
+        PH_LAP(2);
         int b_next = 0;
         if (!QUAD) PH_ADD(2, PH_T() - t_p);   // (ordinary layout: [2] = the passes over the keys, [3] = of which the rounds' collect passes)
         bool bail = false;
@@ -1374,6 +1401,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             __syncthreads();
             const int b0 = (int)s_m, b1 = s_b1;
             __syncthreads();
+            PH_LAP(3);
             if (b1 == 256) break;                 // nothing left
             if (b1 < 0) { bail = true; break; }   // one bucket larger than the chunk: full path
             // ---- a SECOND round starts (the first chunk did not saturate the tile, which is the exception):
@@ -1386,6 +1414,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 __syncthreads();
                 partition_by_bucket(g, n, dmin, shift, b_next, s_cur, ids);
                 partitioned = true;
+                PH_LAP(4);
             }
             // ---- collect the range into LDS grouped by bucket (bucket t starts at the exclusive count of
             //      the buckets before it), depth words relative to the range's base
@@ -1430,6 +1459,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 }
             }
             __syncthreads();
+            PH_LAP(5);
             if (!QUAD) { PH_ADD(2, PH_T() - t_c); PH_ADD(3, PH_T() - t_c); }
             const int m = (int)s_m;
             // ---- order the chunk, then composite it
@@ -1444,6 +1474,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 }
             }
             PH_ADD(0, PH_T() - t_s);
+            PH_LAP(6);
             bool all_done = true;   // ablation build (SAS_TUNE_ABLATE): pretend the first chunk saturates
             if (!(ablate & 2))
                 all_done = blend(m, [&](int i) { return (long long)lo32(ck[i]); });
@@ -1473,6 +1504,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     }
     if (WANT_MAX) store_tile_max(f, tile, ED, s_wmax);
     if (tid == 0) { f.tile_count[tile] = 0; f.tile_big[tile] = 0; }   // the frame's counters leave the frame zeroed (SasFrame invariant)
+    PH_LAP(12);
 #ifdef SAS_TUNE_WGTIME
     if (tid == 0 && blockIdx.x < kDbgWgMax) {
         g_dbg_wg[3 * blockIdx.x] = t_wg0;

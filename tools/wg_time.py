@@ -54,6 +54,20 @@ for cfg in [a if a == "gym" else int(a) for a in sys.argv[1:]] or [3]:
             print(f"  long lists (ordinary layout): passes over the keys {ph[:, 2].sum() * 0.01 / tot:.2f} of the slot time, of which the rounds' collect passes {ph[:, 3].sum() * 0.01 / tot:.2f}")
         print(f"  all workgroups: ordering {ph[:, 0].sum() * 0.01 / tot:.2f}, compositing (staging, masks, queues, trips, waits for the slowest wave) "
               f"{ph[:, 1].sum() * 0.01 / tot:.2f} of the slot time" + (f", wave 0's trips {ph[:, 2].sum() * 0.01 / tot:.2f}" if r.stats()["quad_layout"] else ""))
+    if hasattr(L, "sas_debug_wg_laps") and not r.stats()["quad_layout"]:
+        o16 = (ctypes.c_uint64 * (16 * n))()
+        L.sas_debug_wg_laps(o16, n)
+        lap = np.array(o16, dtype=np.uint64).reshape(n, 16).astype(np.int64) * 0.01   # us
+        names = ["tile order + offsets", "min/max pass", "histogram pass", "bucket selection", "partition", "collect", "chunk ordering",
+                 "first batch: records + barrier", "staging + masks + barrier", "queue building", "trips", "batch barrier (other waves)",
+                 "epilogue", "short list: loads + ordering"]
+        tot = d.sum()
+        print("  exclusive partition of thread 0's time, share of the slot time (all workgroups | lists > 512 | 1..512 | empty):")
+        cls = [np.ones(n, bool), ln > 512, (ln > 0) & (ln <= 512), ln == 0]
+        for k, nm in enumerate(names):
+            print(f"    {nm:32s} " + " | ".join(f"{lap[m, k].sum() / max(d[m].sum(), 1e-9):5.3f}" for m in cls))
+        print(f"    {'(sum of the laps)':32s} " + " | ".join(f"{lap[m].sum() / max(d[m].sum(), 1e-9):5.3f}" for m in cls)
+              + "   class share of slot time: " + " | ".join(f"{d[m].sum() / tot:4.2f}" for m in cls))
     for i in np.argsort(-e)[:3]:
         print(f"  last: launch index {i:5d} list {ln[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} ran {d[i]:6.1f} us")
     for q in (0.25, 0.5, 0.75, 0.9):
