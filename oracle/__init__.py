@@ -65,6 +65,8 @@ def lib():
         _lib.sas_oracle_unproject.restype = None
         _lib.sas_oracle_unproject.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_void_p] * 3
+        _lib.sas_oracle_trace_pixel.restype = ctypes.c_int
+        _lib.sas_oracle_trace_pixel.argtypes = [ctypes.POINTER(_Scene)] + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 2
         _lib.sas_oracle_num_threads.restype = ctypes.c_int
         _lib.sas_oracle_set_variant.argtypes = [ctypes.c_int]
         _lib.sas_oracle_set_num_threads.argtypes = [ctypes.c_int]
@@ -173,13 +175,41 @@ def render(means, opacities, colors, viewmat, K, width: int, height: int, *, qua
                              _ptr(toff), _ptr(sids), cap, _ptr(stats))
     if rc != 0:
         raise MemoryError("oracle allocation failed")
-    out.update(rgb=rgb, alpha=alpha, depth=depth, n_visible=int(stats[0]), n_isect=int(stats[1]), n_isect_tight=int(stats[2]))
+    out.update(rgb=rgb, alpha=alpha, depth=depth, n_visible=int(stats[0]), n_isect=int(stats[1]))
     if want_rgb8:
         out["rgb8"] = rgb8
     if dump:
         out.update(radii=radii, means2d=means2d, depths=depths, conics=conics, colors=cols,
                    tile_offsets=toff, sorted_ids=sids[:cap])
     return out
+
+
+DECISIONS = ("composited", "skipped: alpha < 1/255", "skipped: sigma < 0", "stopped: T' <= 1e-4")
+
+
+def trace_pixel(means, opacities, colors, viewmat, K, width: int, height: int, px: int, py: int, variant_a: int, variant_b: int, *,
+                quats=None, scales=None, cov6=None, sh_degree: int = 3, group_id=None, group_Rt=None) -> Dict[str, object]:
+    """Where two variant masks part on pixel (px, py): the first list entry whose DECISION differs (deviation study)."""
+    L = lib()
+    means = _f32(means, (-1, 3))
+    n = means.shape[0]
+    quats, scales, cov6 = _f32(quats, (-1, 4)), _f32(scales, (-1, 3)), _f32(cov6, (-1, 6))
+    opacities = _f32(opacities, (-1,))
+    kk = (sh_degree + 1) ** 2 if sh_degree >= 0 else 1
+    colors = _f32(colors, (n, kk, 3))
+    gid = None if group_id is None else np.ascontiguousarray(np.asarray(group_id, dtype=np.uint8))
+    gRt = _f32(group_Rt, (-1, 12))
+    sc = _Scene(n, _ptr(means), _ptr(quats), _ptr(scales), _ptr(cov6), _ptr(opacities), _ptr(colors),
+                int(sh_degree), _ptr(gid), 0 if gRt is None else gRt.shape[0], _ptr(gRt))
+    V, Km = _f32(viewmat, (16,)), _f32(K, (9,))
+    out = np.zeros(4, np.int64)
+    vals = np.zeros(6, np.float32)
+    if L.sas_oracle_trace_pixel(ctypes.byref(sc), _ptr(V), _ptr(Km), int(width), int(height), int(px), int(py), int(variant_a),
+                                int(variant_b), _ptr(out), _ptr(vals)) != 0:
+        raise MemoryError("oracle allocation failed")
+    return dict(entry=int(out[0]), gaussian=int(out[1]), decision_a=DECISIONS[int(out[2])], decision_b=DECISIONS[int(out[3])],
+                alpha_a=float(vals[0]), alpha_b=float(vals[1]), next_T_a=float(vals[2]), next_T_b=float(vals[3]),
+                sigma_a=float(vals[4]), sigma_b=float(vals[5]))
 
 
 def unproject(depth, K, max_depth=1.0):

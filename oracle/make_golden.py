@@ -131,6 +131,37 @@ def gen_twin_renders():
         print(f"{name}: visible {out['n_visible']}, intersections {out['n_isect']}, saturated pixels (T < 1e-3) {term} of {cam.width * cam.height}")
 
 
+def gen_cfg3_crop(tiles_x=8, tiles_y=6):
+    """The float64 twin on BASELINE config 3 ITSELF (1 M Gaussians, 1920x1080, view 0): a window of tiles_x x tiles_y
+    tiles placed on the densest part of the frame (largest sum of list lengths, from the C oracle's tile offsets),
+    rendered from the Gaussians whose tile rectangle touches it.  The scene is seeded (config_scene_and_cameras(3)),
+    so the fixture holds the window and the twin's frames only."""
+    import oracle
+    from oracle import np_twin
+    from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND, config_scene_and_cameras
+    sc, cams = config_scene_and_cameras(3)
+    cam = cams[0]
+    ref = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats, scales=sc.scales,
+                        sh_degree=sc.sh_degree, background=NERFSTUDIO_EVAL_BACKGROUND, dump=True)
+    tw, th = (cam.width + 15) // 16, (cam.height + 15) // 16
+    cnt = np.diff(ref["tile_offsets"].astype(np.int64)).reshape(th, tw)
+    S = np.zeros((th + 1, tw + 1), np.int64)
+    S[1:, 1:] = cnt.cumsum(0).cumsum(1)
+    win = S[tiles_y:, tiles_x:] - S[:-tiles_y, tiles_x:] - S[tiles_y:, :-tiles_x] + S[:-tiles_y, :-tiles_x]
+    ty0, tx0 = np.unravel_index(int(win.argmax()), win.shape)
+    crop = (int(tx0), int(ty0), int(tx0) + tiles_x, int(ty0) + tiles_y)
+    out = np_twin.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats, scales=sc.scales,
+                         sh_degree=sc.sh_degree, background=NERFSTUDIO_EVAL_BACKGROUND, crop=crop)
+    assert out["n_isect"] == int(cnt[crop[1]:crop[3], crop[0]:crop[2]].sum()), "twin and C oracle bin the window differently"
+    np.savez_compressed(GOLD / "render_twin_cfg3_crop.npz", config=np.int32(3), view=np.int32(0), crop_tiles=np.array(crop, np.int32),
+                        wh=np.array([cam.width, cam.height]), background=np.array(NERFSTUDIO_EVAL_BACKGROUND, np.float32),
+                        rgb=out["rgb"].astype(np.float32), alpha=out["alpha"].astype(np.float32), depth=out["depth"].astype(np.float32),
+                        n_isect=np.int64(out["n_isect"]), tile_lengths=cnt[crop[1]:crop[3], crop[0]:crop[2]].astype(np.int32))
+    sat = int(((1.0 - out["alpha"]) < 1e-3).sum())
+    print(f"cfg3 crop tiles {crop}: {out['n_isect']} intersections (lists {cnt[crop[1]:crop[3], crop[0]:crop[2]].min()}..{cnt[crop[1]:crop[3], crop[0]:crop[2]].max()}), "
+          f"saturated pixels {sat} of {out['alpha'].size}")
+
+
 ASSETS = Path("/root/reference/assets/robots-scene-v2")
 
 
@@ -189,5 +220,8 @@ if __name__ == "__main__":
         gen_scene_assets()
         gen_scene_assets_divar()
         gen_run_files()
-    if "--assets-only" not in sys.argv:
+    if "--cfg3-crop" in sys.argv:
+        gen_cfg3_crop()
+    elif "--assets-only" not in sys.argv:
         gen_twin_renders()
+        gen_cfg3_crop()

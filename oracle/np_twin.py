@@ -4,7 +4,8 @@ Same algorithm, written independently with libm/NumPy 
 precision and no operation-order contract.  It cross-checks the C oracle: continuous outputs
 must agree to ~1e-5, and a pixel may differ more only through a threshold decision
 (alpha < 1/255, T <= 1e-4) taken on a value within float32 rounding of the threshold.
-Sized for small scenes (<= a few thousand Gaussians, <= 256x256).
+Sized for small scenes (<= a few thousand Gaussians, <= 256x256) -- or, with ``crop``, for a window of tiles of a
+large frame (the config-3 golden: tests/golden/render_twin_cfg3_crop.npz).
 """
 from __future__ import annotations
 
@@ -135,9 +136,11 @@ def project(means, opacities, colors, viewmat, K, W, H, quats=None, scales=None,
 
 def render(means, opacities, colors, viewmat, K, width, height, quats=None, scales=None, cov6=None,
            sh_degree=3, group_id=None, group_Rt=None, background=(0, 0, 0), depth_mode=0,
-           depth_key_f32: bool = True) -> Dict[str, np.ndarray]:
+           depth_key_f32: bool = True, crop=None) -> Dict[str, np.ndarray]:
     """Full frame in float64.  ``depth_key_f32`` sorts by the float32 depth (as every f32
-    implementation does) so that near-ties order identically; ties fall back to index."""
+    implementation does) so that near-ties order identically; ties fall back to index.
+    ``crop = (tx0, ty0, tx1, ty1)``: only that window of 16-pixel tiles is rendered (from the Gaussians whose tile
+    rectangle touches it); the frames returned are the window's pixels, ``n_isect`` its intersections."""
     W, H = int(width), int(height)
     P = project(means, opacities, colors, viewmat, K, W, H, quats, scales, cov6, sh_degree, group_id, group_Rt)
     tw, th = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
@@ -148,9 +151,12 @@ def render(means, opacities, colors, viewmat, K, width, height, quats=None, scal
     y0 = np.clip(np.floor((m2[:, 1] - rad[:, 1]) / TILE), 0, th).astype(int)
     y1 = np.clip(np.ceil((m2[:, 1] + rad[:, 1]) / TILE), 0, th).astype(int)
     lists = [[] for _ in range(tw * th)]
+    cx0, cy0, cx1, cy1 = (0, 0, tw, th) if crop is None else [int(v) for v in crop]
+    if crop is not None:
+        vis = vis[(x1[vis] > cx0) & (x0[vis] < cx1) & (y1[vis] > cy0) & (y0[vis] < cy1)]
     for i in vis:
-        for ty in range(y0[i], y1[i]):
-            for tx in range(x0[i], x1[i]):
+        for ty in range(max(y0[i], cy0), min(y1[i], cy1)):
+            for tx in range(max(x0[i], cx0), min(x1[i], cx1)):
                 lists[ty * tw + tx].append(i)
     dkey = P["depths"].astype(np.float32) if depth_key_f32 else P["depths"]
     bg = np.asarray(background, np.float64)
@@ -160,6 +166,8 @@ def render(means, opacities, colors, viewmat, K, width, height, quats=None, scal
     n_isect = 0
     for t, ids in enumerate(lists):
         ty, tx = divmod(t, tw)
+        if not (cx0 <= tx < cx1 and cy0 <= ty < cy1):
+            continue
         ys = np.arange(ty * TILE, min((ty + 1) * TILE, H))
         xs = np.arange(tx * TILE, min((tx + 1) * TILE, W))
         px, py = np.meshgrid(xs + 0.5, ys + 0.5)
@@ -193,4 +201,7 @@ def render(means, opacities, colors, viewmat, K, width, height, quats=None, scal
         rgb[sl] = np.clip(acc[..., :3] + (1 - a_out)[..., None] * bg, 0, 1)
     if depth_mode == 1:
         depth = np.where(alpha > 0, depth, depth.max())
+    if crop is not None:
+        win = (slice(cy0 * TILE, min(cy1 * TILE, H)), slice(cx0 * TILE, min(cx1 * TILE, W)))
+        rgb, alpha, depth = rgb[win], alpha[win], depth[win]
     return dict(rgb=rgb, alpha=alpha, depth=depth, n_visible=len(vis), n_isect=n_isect, proj=P)

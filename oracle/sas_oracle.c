@@ -40,6 +40,7 @@
 #endif
 
 #define OC_TILE 16
+#define OC_TILE_CENTRE 8.0f   /* the tile-local frame of T6's sigma polynomial has its origin at the tile's centre */
 #define OC_NEAR 0.01f
 #define OC_FAR 1e10f
 #define OC_EPS2D 0.3f
@@ -379,48 +380,15 @@ static inline void tile_rect(const proj_t *p, const cam_t *c, int *x0, int *x1, 
     *y1 = (int)fminf(fmaxf(fy1, 0.0f), th);
 }
 
-/* Tight tiles (the product's binning; the image does not depend on it).  gsplat bins a Gaussian into every tile of its
- * bounding rectangle; the product skips the tiles none of whose pixel centres can reach alpha >= 1/255, i.e. where the
- * minimum of sigma over the rectangle spanned by the tile's pixel centres exceeds thr + 0.05.  For a mean outside that
- * rectangle the minimum of the convex quadratic lies on an edge facing the mean (at most two), at the clamped
- * stationary point of the edge.  Same operations in the same order as tile_reached() of csrc/sas_device.h: the tight
- * intersection count (stats[2]) is compared with the product's n_isect exactly. */
-typedef struct { float mx, my, A, B, C, lim, nba, nbc; } reach_t;
-
-static inline reach_t reach_of(const proj_t *p)
-{
-    reach_t g = {p->mx, p->my, p->ca, p->cb, p->cc, p->thr + 0.05f, -p->cb / p->ca, -p->cb / p->cc};
-    return g;
-}
-
-static inline int tile_reached(const reach_t *g, int tx, int ty)
-{
-    const float x0 = (float)(tx * OC_TILE) + 0.5f, y0 = (float)(ty * OC_TILE) + 0.5f;
-    const float dx0 = x0 - g->mx, dx1 = (x0 + 15.0f) - g->mx, dy0 = y0 - g->my, dy1 = (y0 + 15.0f) - g->my;
-    const int in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;
-    if (in_x && in_y) return 1;
-    const float hA = 0.5f * g->A, hC = 0.5f * g->C;
-    float best = INFINITY;
-    if (!in_x) {
-        const float dx = dx0 > 0.0f ? dx0 : dx1;
-        const float dy = fminf(fmaxf(g->nbc * dx, dy0), dy1);
-        best = fmaf(g->B * dx, dy, fmaf(hC * dy, dy, (hA * dx) * dx));
-    }
-    if (!in_y) {
-        const float dy = dy0 > 0.0f ? dy0 : dy1;
-        const float dx = fminf(fmaxf(g->nba * dy, dx0), dx1);
-        best = fminf(best, fmaf(g->B * dx, dy, fmaf(hA * dx, dx, (hC * dy) * dy)));
-    }
-    return !(best > g->lim);
-}
-
 static int cmp_u64(const void *a, const void *b)
 {
     uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
     return (x > y) - (x < y);
 }
 
-/* T6, per (Gaussian, tile): sigma as a polynomial in the tile-local pixel centre (x, y),
+/* T6, per (Gaussian, tile): sigma as a polynomial in the pixel centre (x, y) RELATIVE TO THE TILE'S CENTRE (X0, Y0)
+ * (x, y in -7.5 .. 7.5: the terms that cancel are a quarter of what they are about the tile's corner, and with them
+ * the rounding of the sum -- 40x fewer pixels moved by more than 1e-6 against the textbook form, tests/tools/deviation_table.py),
  *   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
  *   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2
  * (algebraically gsplat's 0.5 (A dx^2 + C dy^2) + B dx dy with dx = mx - px; the conic is positive
@@ -445,7 +413,7 @@ static inline void blend_pixel(const proj_t *P, const int32_t *ids, const tcoef_
                                float out_acc[4], float *out_T)
 {
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, ad = 0.0f;
-    const float xx = x * x, yy = y * y, xy = x * y; /* exact: multiples of 0.25 below 256 */
+    const float xx = x * x, yy = y * y, xy = x * y; /* exact: multiples of 0.25 below 64 */
     for (int64_t k = 0; k < n; ++k) {
         const proj_t *g = &P[ids[k]];
         const tcoef_t *t = &tc[k];
@@ -509,12 +477,87 @@ static inline void blend_pixel_variant(int variant, const proj_t *P, const int32
     *out_T = T;
 }
 
+/* ---- deviation study, one pixel: WHERE two variants part (tests/test_oracle.py) --------------------------------
+ * Replays the list of pixel (px, py)'s tile under variant masks va and vb side by side and reports the first entry at
+ * which their DECISIONS differ (0 composited, 1 skipped: alpha < 1/255, 2 skipped: sigma < 0 guard, 3 stopped: T' <= 1e-4).
+ * Two float32 evaluations of one formula can only part company by more than rounding noise through such a flip; the
+ * test shows, for every pixel that differs by more than the tolerance, the flipped splat and how close both sides sat
+ * to the threshold.  out = {entry k (-1: no decision differs), Gaussian index, decision a, decision b},
+ * vals = {alpha a, alpha b, T' a, T' b, sigma a, sigma b}.  Returns 0, -1 on allocation failure. */
+static inline int decide_variant(int variant, const proj_t *g, const tcoef_t *t, float x, float y, float px, float py, float T,
+                                 float *o_alpha, float *o_nT, float *o_sigma)
+{
+    float sigma;
+    if (variant & 1) {
+        float dx = g->mx - px, dy = g->my - py;
+        sigma = 0.5f * (g->ca * dx * dx + g->cc * dy * dy) + g->cb * dx * dy;
+    } else {
+        const float xx = x * x, yy = y * y, xy = x * y;
+        sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
+    }
+    *o_sigma = sigma;
+    *o_alpha = 0.0f;
+    *o_nT = T;
+    if ((variant & 2) && sigma < 0.0f) return 2;
+    float e = (variant & 8) ? expf(-sigma) : sas_oracle_expf(-sigma);
+    float alpha = fminf(OC_MAX_ALPHA, g->opac * e);
+    *o_alpha = alpha;
+    if (alpha < OC_ALPHA_THRESHOLD) return 1;
+    float vis = alpha * T;
+    float next_T = (variant & 4) ? T * (1.0f - alpha) : T - vis;
+    *o_nT = next_T;
+    if (next_T <= OC_T_STOP) return 3;
+    return 0;
+}
+
+int sas_oracle_trace_pixel(const sas_oracle_scene *s, const float viewmat[16], const float K[9], int W, int H, int px, int py,
+                           int va, int vb, int64_t out[4], float vals[6])
+{
+    cam_t c;
+    cam_from(viewmat, K, W, H, &c);
+    const int64_t n = s->n;
+    const int tx = px / OC_TILE, ty = py / OC_TILE;
+    proj_t *P = (proj_t *)malloc(sizeof(proj_t) * (size_t)(n > 0 ? n : 1));
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    if (!P || !keys) { free(P); free(keys); return -1; }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) project_one(s, &c, i, &P[i]);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (P[i].rx <= 0 || P[i].ry <= 0) continue;
+        int x0, x1, y0, y1;
+        tile_rect(&P[i], &c, &x0, &x1, &y0, &y1);
+        if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) keys[m++] = ((uint64_t)f2u(P[i].depth) << 32) | (uint64_t)(uint32_t)i;
+    }
+    qsort(keys, (size_t)m, sizeof(uint64_t), cmp_u64);
+    const float x = (float)(px - tx * OC_TILE) + 0.5f - OC_TILE_CENTRE, y = (float)(py - ty * OC_TILE) + 0.5f - OC_TILE_CENTRE;
+    float Ta = 1.0f, Tb = 1.0f;
+    out[0] = -1; out[1] = -1; out[2] = 0; out[3] = 0;
+    for (int k = 0; k < 6; ++k) vals[k] = 0.0f;
+    for (int64_t k = 0; k < m; ++k) {
+        const proj_t *g = &P[(uint32_t)(keys[k] & 0xffffffffu)];
+        tcoef_t t;
+        tile_coefs(g, (float)(tx * OC_TILE) + OC_TILE_CENTRE, (float)(ty * OC_TILE) + OC_TILE_CENTRE, &t);
+        float aa, ab, na, nb, sa, sb;
+        const int da = decide_variant(va, g, &t, x, y, (float)px + 0.5f, (float)py + 0.5f, Ta, &aa, &na, &sa);
+        const int db = decide_variant(vb, g, &t, x, y, (float)px + 0.5f, (float)py + 0.5f, Tb, &ab, &nb, &sb);
+        if (da != db) {
+            out[0] = k; out[1] = (int64_t)(uint32_t)(keys[k] & 0xffffffffu); out[2] = da; out[3] = db;
+            vals[0] = aa; vals[1] = ab; vals[2] = na; vals[3] = nb; vals[4] = sa; vals[5] = sb;
+            break;
+        }
+        if (da == 3) break;
+        if (da == 0) { Ta = na; Tb = nb; }
+    }
+    free(P); free(keys);
+    return 0;
+}
+
 /*
  * Full frame.  depth_mode: 0 = expected depth ED = acc_d / max(alpha,1e-10) (gsplat "RGB+ED");
  *              1 = nerfstudio fill, where(alpha > 0, ED, max(ED)).
  * Optional outputs may be NULL.  Projection dumps are [n]-sized; tile_offsets is [tiles+1];
- * sorted_ids receives at most sorted_cap entries.  stats = {n_visible, n_intersections (gsplat's rectangles),
- * n_intersections of the tight binning}.
+ * sorted_ids receives at most sorted_cap entries.  stats = {n_visible, n_intersections (gsplat's rectangles), 0}.
  * Returns 0, or -1 on allocation failure.
  */
 int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const float K[9], int W, int H,
@@ -534,18 +577,14 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) project_one(s, &c, i, &P[i]);
 
-    int64_t n_vis = 0, m_tight = 0;
+    int64_t n_vis = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (P[i].rx <= 0 || P[i].ry <= 0) continue; /* gsplat isect_tiles: radius_x <= 0 || radius_y <= 0 */
         ++n_vis;
         int x0, x1, y0, y1;
         tile_rect(&P[i], &c, &x0, &x1, &y0, &y1);
-        const reach_t rg = reach_of(&P[i]);
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
-                tcount[ty * c.tw + tx + 1]++;
-                m_tight += tile_reached(&rg, tx, ty);
-            }
+            for (int tx = x0; tx < x1; ++tx) tcount[ty * c.tw + tx + 1]++;
     }
     for (int t = 0; t < tiles; ++t) tcount[t + 1] += tcount[t];
     const int64_t M = tcount[tiles];
@@ -584,7 +623,9 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         const int32_t *tl = ids + tcount[t];
         int64_t tn = tcount[t + 1] - tcount[t];
         tcoef_t *tc = tc_all + (size_t)oc_thread_id() * (size_t)max_len;
-        for (int64_t k = 0; k < tn; ++k) tile_coefs(&P[tl[k]], (float)(tx * OC_TILE), (float)(ty * OC_TILE), &tc[k]);
+        /* the polynomial is taken about the tile's CENTRE (variant 16: about its corner, the form of rounds 1-3, for the study) */
+        const float cen = (g_variant & 16) ? 0.0f : OC_TILE_CENTRE;
+        for (int64_t k = 0; k < tn; ++k) tile_coefs(&P[tl[k]], (float)(tx * OC_TILE) + cen, (float)(ty * OC_TILE) + cen, &tc[k]);
         for (int yy = 0; yy < OC_TILE; ++yy) {
             int i = ty * OC_TILE + yy;
             if (i >= H) break;
@@ -592,8 +633,8 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
                 int j = tx * OC_TILE + xx;
                 if (j >= W) break;
                 float acc[4], T;
-                if (g_variant == 0) blend_pixel(P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f, acc, &T);
-                else blend_pixel_variant(g_variant, P, tl, tc, tn, (float)xx + 0.5f, (float)yy + 0.5f,
+                if (g_variant == 0) blend_pixel(P, tl, tc, tn, (float)xx + 0.5f - cen, (float)yy + 0.5f - cen, acc, &T);
+                else blend_pixel_variant(g_variant, P, tl, tc, tn, (float)xx + 0.5f - cen, (float)yy + 0.5f - cen,
                                          (float)j + 0.5f, (float)i + 0.5f, acc, &T);
                 float a = 1.0f - T;
                 int64_t pix = (int64_t)i * W + j;
@@ -638,7 +679,7 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         int64_t m = M < sorted_cap ? M : sorted_cap;
         memcpy(o_sorted_ids, ids, sizeof(int32_t) * (size_t)m);
     }
-    if (stats) { stats[0] = n_vis; stats[1] = M; stats[2] = m_tight; }
+    if (stats) { stats[0] = n_vis; stats[1] = M; stats[2] = 0; }
     free(P); free(tcount); free(keys); free(ids); free(cursor); free(tc_all);
     return 0;
 }

@@ -470,22 +470,25 @@ DEV unsigned block_mask4(int tx, int ty, int qd, float mx, float my, float A, fl
     return m;
 }
 
-// Per-pixel compositing state.  x is the pixel centre relative to the tile origin.  A terminated
+// Per-pixel compositing state.  x is the pixel centre relative to the tile's centre.  A terminated
 // pixel (transmittance test fired, or outside the image) is parked at x = NaN: every later sigma is
 // then NaN and fails `sigma <= thr` by itself, so the inner loop carries no "done" flag.
 struct PixState {
     float T, r, g, b, d;
     float x;
 };
-// loop-invariant powers of the pixel's tile-local centre (exact: multiples of 0.25 below 256)
+// loop-invariant powers of the pixel's tile-local centre (exact: multiples of 0.25 below 64)
 struct PixConst {
     float y, xx, yy, xy;
 };
 DEV bool pix_dead(const PixState &p) { return p.x != p.x; }
-DEV PixState pix_init(bool inside, int ox) { return PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? (float)ox + 0.5f : __builtin_nanf("")}; }
+// Contract T6: the sigma polynomial's frame has its origin at the CENTRE of the 16-pixel tile (x, y in -7.5 .. 7.5: the
+// cancelling terms, and with them the rounding of the sum, are a quarter of what they are about the tile's corner)
+constexpr float kTileCentre = 8.0f;
+DEV PixState pix_init(bool inside, int ox) { return PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? ((float)ox + 0.5f) - kTileCentre : __builtin_nanf("")}; }
 DEV PixConst pix_const(int ox, int oy)
 {
-    const float x = (float)ox + 0.5f, y = (float)oy + 0.5f;
+    const float x = ((float)ox + 0.5f) - kTileCentre, y = ((float)oy + 0.5f) - kTileCentre;
     return PixConst{y, x * x, y * y, x * y};
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
@@ -627,7 +630,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         L.q1[256] = make_float4(z0, z0, m1, z0);
         L.q2[256] = make_float4(z0, z0, z0, z0);
     }
-    const float X0 = (float)(tx * SAS_TILE), Y0 = (float)(ty * SAS_TILE);
+    const float X0 = (float)(tx * SAS_TILE) + kTileCentre, Y0 = (float)(ty * SAS_TILE) + kTileCentre;   // the polynomial's origin: the tile's centre
     // this lane's block: bit in the entry masks, and its queue
     const int grp = lane >> 4;
     const int my_bit = ((wv & 1) * 2 + (grp & 1)) + 4 * ((wv >> 1) * 2 + (grp >> 1));
@@ -872,7 +875,7 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
         L.q1[256] = make_float4(z0, z0, m1, z0);
         L.q2[256] = make_float4(z0, z0, z0, z0);
     }
-    const float X0 = (float)(tx * SAS_TILE), Y0 = (float)(ty * SAS_TILE);
+    const float X0 = (float)(tx * SAS_TILE) + kTileCentre, Y0 = (float)(ty * SAS_TILE) + kTileCentre;   // the polynomial's origin: the tile's centre
     const int e = lane & 3;
     unsigned short *wq = L.queue + wv * 1024;   // this wave's queue: 256 entries (+ the look-ahead's slack inside its 1024)
     const char *q0b = reinterpret_cast<const char *>(L.q0);
