@@ -119,8 +119,9 @@ class SplatHandler:
         self._k_fast = min(len(self.fk), 7, len(self.splat_links_handler))
         self._fast = hasattr(self.scene, "set_link_poses") and self._k_fast > 0
         if self._fast:
+            # kept by the scene under THIS handler's key: a second handler on the same scene has constants of its own
             self.scene.set_link_constants(self.scale_factor, self.Ri, self.ti, self._fkR[:self._k_fast], self._fkt[:self._k_fast],
-                                          self.weld_translation, [h.index for h in self.splat_links_handler[:self._k_fast]])
+                                          self.weld_translation, [h.index for h in self.splat_links_handler[:self._k_fast]], owner=id(self))
 
     @classmethod
     def from_assets(cls, loader, masks_dir, urdf_path, bounds=None, **kw) -> "SplatHandler":
@@ -152,12 +153,12 @@ class SplatHandler:
         if k == 0:
             return
         if self._fast and idxs[k - 1] == k - 1:          # the robot's links lead the message (Drake's order): no gather
-            self.scene.set_link_poses(msg.quaternion[:k], msg.position[:k])
+            self.scene.set_link_poses(msg.quaternion[:k], msg.position[:k], owner=id(self))
             return
         q = np.asarray([msg.quaternion[i] for i in idxs[:k]], dtype=np.float64)
         p = np.asarray([msg.position[i] for i in idxs[:k]], dtype=np.float64)
         if self._fast:
-            self.scene.set_link_poses(q, p)      # float64 in C, the arithmetic below; handles read their rows back on demand
+            self.scene.set_link_poses(q, p, owner=id(self))      # float64 in C, the arithmetic below; handles read their rows back on demand
             return
         R, t = poses.link_splat_poses(self.scale_factor, self.Ri, self.ti, self._fkR[:k], self._fkt[:k], q, p, self.weld_translation)
         wxyz = poses.matrices_to_quats_wxyz(R)
@@ -184,7 +185,7 @@ class SplatHandler:
             local_xyz = np.asarray(local_frame_pos, dtype=np.float64).reshape(3)
         idx = msg.link_name.index("plant::" + body_name) if isinstance(msg.link_name, list) else list(msg.link_name).index("plant::" + body_name)
         if self._fast and hasattr(self.scene, "attached_frame"):
-            return self.scene.attached_frame(msg.quaternion[idx], msg.position[idx], local_xyz)
+            return self.scene.attached_frame(msg.quaternion[idx], msg.position[idx], local_xyz, owner=id(self))
         R, t = poses.attached_frame(self.scale_factor, self.Ri, self.ti, msg.quaternion[idx], msg.position[idx], local_xyz)
         return poses.matrix_to_quat_wxyz(R), t
 

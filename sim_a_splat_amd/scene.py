@@ -67,6 +67,9 @@ class GaussianSplatHandle:
             self._write_row()
 
 
+_NO_OWNER_APPLIED = object()   # SplatScene._link_owner_applied: the library's context holds nobody's link constants
+
+
 class _Camera:
     def __init__(self):
         self.wxyz = np.array([1.0, 0.0, 0.0, 0.0])
@@ -92,7 +95,11 @@ class SplatScene:
         self._poses_dirty = True
         self._Rt = np.zeros((0, 3, 4), np.float32)     # all group poses, the block that goes to the GPU
         self._links_gen = 0                            # bumped when set_link_poses rewrites the block
-        self._link_consts = None
+        # constants of the link-pose algebra PER OWNER (a SplatHandler: its ICP similarity, forward kinematics, weld, groups).
+        # The library's context holds one set; the scene applies the caller's before each use, so that two handlers on one
+        # scene (two robots, `instance_uid`) never pose their links or cameras with each other's constants.
+        self._link_consts: Dict[object, tuple] = {}
+        self._link_owner_applied = _NO_OWNER_APPLIED
         self.background = tuple(background)
         self.camera = _Camera()
 
@@ -118,22 +125,33 @@ class SplatScene:
         return h
 
     # -- the draw message's pose algebra inside the library (SplatHandler.draw_handler's fast path) ---------------
-    def set_link_constants(self, scale: float, Ri, ti, Rfk, tfk, weld=None, groups=None) -> None:
-        """See ``Rasterizer.set_link_constants``; kept and re-applied whenever the scene is uploaded again."""
+    def set_link_constants(self, scale: float, Ri, ti, Rfk, tfk, weld=None, groups=None, owner=None) -> None:
+        """See ``Rasterizer.set_link_constants``; kept per ``owner`` (the handler they belong to) and applied to the
+        library's context whenever that owner's poses or cameras are evaluated next."""
         with self.lock:
-            self._link_consts = (float(scale), np.array(Ri, np.float64), np.array(ti, np.float64), np.array(Rfk, np.float64),
-                                 np.array(tfk, np.float64), None if weld is None else np.array(weld, np.float64),
-                                 None if groups is None else np.array(groups, np.int32))
-            if self._uploaded:
-                self._raster.set_link_constants(*self._link_consts)
+            self._link_consts[owner] = (float(scale), np.array(Ri, np.float64), np.array(ti, np.float64), np.array(Rfk, np.float64),
+                                        np.array(tfk, np.float64), None if weld is None else np.array(weld, np.float64),
+                                        None if groups is None else np.array(groups, np.int32))
+            if self._link_owner_applied is owner or self._link_owner_applied == owner:
+                self._link_owner_applied = _NO_OWNER_APPLIED   # re-apply on the next use
 
-    def set_link_poses(self, q_msg, p_msg) -> None:
+    def _apply_link_constants(self, owner) -> None:
+        """(lock held, scene uploaded)  Make ``owner``'s constants the ones the library's context holds."""
+        if owner not in self._link_consts:
+            raise RuntimeError("set_link_constants first")
+        if self._link_owner_applied is _NO_OWNER_APPLIED or self._link_owner_applied != owner:
+            self._raster.set_link_constants(*self._link_consts[owner])
+            self._link_owner_applied = owner
+
+    def set_link_poses(self, q_msg, p_msg, owner=None) -> None:
         """The first k links' message poses -> their groups' poses (sas_set_link_poses: float64 in C, the arithmetic of
-        ``poses.link_splat_poses`` + the quaternion round trip of the handles); the other groups keep theirs."""
+        ``poses.link_splat_poses`` + the quaternion round trip of the handles), with ``owner``'s constants; the other
+        groups keep theirs."""
         with self.lock:
-            if self._link_consts is None:
+            if owner not in self._link_consts:
                 raise RuntimeError("set_link_constants first")
             self._sync()                                    # scene + whatever the handles were assigned since
+            self._apply_link_constants(owner)
             self._raster.set_link_poses(q_msg, p_msg, out=self._Rt.reshape(-1))
             self._links_gen += 1
 
@@ -151,8 +169,7 @@ class SplatScene:
                                     sh_degree=-1, group_id=gid, n_groups=len(self._groups))
             self._uploaded = True
             self._poses_dirty = True
-            if self._link_consts is not None and self._groups:
-                self._raster.set_link_constants(*self._link_consts)
+            self._link_owner_applied = _NO_OWNER_APPLIED    # a fresh upload: the context holds nobody's link constants
         if self._poses_dirty and self._groups:
             self._raster.set_group_poses(self._Rt.reshape(-1, 12))
         self._poses_dirty = False
@@ -206,12 +223,13 @@ class SplatScene:
             # land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
             return self._raster.render_cameras_host(qp[0], qp[1, :, :3], f, int(width), int(height), self.background).numpy()
 
-    def attached_frame(self, q_link, p_link, local_xyz):
-        """(wxyz, xyz) of a camera riding on a link, with the similarity of ``set_link_constants`` (sas_link_attached_frame)."""
+    def attached_frame(self, q_link, p_link, local_xyz, owner=None):
+        """(wxyz, xyz) of a camera riding on a link, with the similarity of ``owner``'s ``set_link_constants`` (sas_link_attached_frame)."""
         with self.lock:
-            if self._link_consts is None:
+            if owner not in self._link_consts:
                 raise RuntimeError("set_link_constants first")
             self._sync()
+            self._apply_link_constants(owner)
             return self._raster.link_attached_frame(q_link, p_link, local_xyz)
 
     def get_render_float(self, height: int, width: int, wxyz, position, fov: Optional[float] = None) -> Dict[str, torch.Tensor]:
