@@ -16,12 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
-    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
+    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1 -- or, with ``force``, also for a
+    single rank (the one-GPU rehearsal of the RCCL path: a world of one still runs every collective through RCCL)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -46,14 +47,17 @@ class FrameGather:
     frame i with the rendering of frame i+1.
     """
 
-    def __init__(self, world: int, rank: int, dst: int = 0):
+    def __init__(self, world: int, rank: int, dst: int = 0, collective: Optional[bool] = None):
         self.world, self.rank, self.dst = world, rank, dst
+        # a single rank keeps its frame (no process group needed) -- unless `collective` asks for the real gather, which a
+        # world of one still runs through the backend (RCCL): the one-GPU rehearsal of the multi-GPU path
+        self.collective = world > 1 if collective is None else bool(collective)
         self._work = None
         self._bufs: Optional[List[torch.Tensor]] = None
-        self._via_host = world > 1 and dist.get_backend() == "gloo"   # gloo cannot gather device tensors
+        self._via_host = self.collective and dist.get_backend() == "gloo"   # gloo cannot gather device tensors
 
     def start(self, frame: torch.Tensor):
-        if self.world <= 1:
+        if not self.collective:
             self._bufs = [frame]
             return
         self.finish()
@@ -87,14 +91,14 @@ class StepPipeline:
     """
 
     def __init__(self, world: int, rank: int, buffers: Sequence, submit, steps_completed, wait, payload=lambda b: b,
-                 on_gathered=None):
+                 on_gathered=None, collective: Optional[bool] = None):
         if len(buffers) < 2:
             raise ValueError("need at least two buffers")
         self.world, self.rank = world, rank
         self.bufs = list(buffers)
         self._submit, self._completed, self._wait, self._payload = submit, steps_completed, wait, payload
         self._on_gathered = on_gathered
-        self.gather = FrameGather(world, rank)
+        self.gather = FrameGather(world, rank, collective=collective)
         self.base = 0          # steps_completed() at the start of this run
         self.submitted = 0     # steps submitted in this run
         self.gathered = 0      # steps whose gather has been started
@@ -107,13 +111,13 @@ class StepPipeline:
 
     def _finish_gather(self) -> None:
         got = self.gather.finish()
-        if self._reading is not None and self._on_gathered is not None and self.world > 1:
+        if self._reading is not None and self._on_gathered is not None and self.gather.collective:
             self._on_gathered(self._reading, got)
         self._reading = None
 
     def _start_gathers(self, upto: int) -> None:
         while self.gathered < upto:
-            if self.world > 1:
+            if self.gather.collective:
                 self._finish_gather()
                 self.gather.start(self._payload(self.bufs[self.gathered % len(self.bufs)]))
                 self._reading = self.gathered
@@ -135,11 +139,11 @@ class StepPipeline:
         """Complete every submitted step and gather what is left."""
         self._wait()
         self._start_gathers(self.submitted)
-        if self.world > 1:
+        if self.gather.collective:
             self._finish_gather()
 
 
-def frame_meta(frames: Sequence[torch.Tensor], rank: int, world: int, src: int = 0):
+def frame_meta(frames: Sequence[torch.Tensor], rank: int, world: int, src: int = 0, collective: Optional[bool] = None):
     """(shape, dtype) of the frames being gathered, agreed over all ranks: a rank that owns no view
     (n_views < world) has no frame to read them from, so rank ``src`` (which always owns view 0)
     broadcasts them."""
@@ -148,25 +152,26 @@ def frame_meta(frames: Sequence[torch.Tensor], rank: int, world: int, src: int =
         if not frames:
             raise ValueError("the source rank owns view 0 and must pass its frame")
         meta = [(tuple(frames[0].shape), frames[0].dtype)]
-    if world > 1:
+    if world > 1 or collective:
         dist.broadcast_object_list(meta, src=src)
     return meta[0]
 
 
-def gather_frames(frames: Sequence[torch.Tensor], n_views: int, rank: int, world: int) -> Optional[List[torch.Tensor]]:
+def gather_frames(frames: Sequence[torch.Tensor], n_views: int, rank: int, world: int,
+                  collective: Optional[bool] = None) -> Optional[List[torch.Tensor]]:
     """Synchronous helper: every rank passes the frames of its ``shard_views`` views (same shape; a
     rank without views passes an empty list); rank 0 gets the list of all ``n_views`` frames in view
-    order."""
-    if world <= 1:
+    order.  ``collective=True`` runs the gathers through the backend even for a world of one."""
+    if world <= 1 and not collective:
         return list(frames)
-    shape, dtype = frame_meta(frames, rank, world)
+    shape, dtype = frame_meta(frames, rank, world, collective=collective)
     if frames:
         device = frames[0].device
     else:   # RCCL gathers device tensors, gloo host tensors
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     rounds = (n_views + world - 1) // world
     out: List[Optional[torch.Tensor]] = [None] * n_views
-    g = FrameGather(world, rank)
+    g = FrameGather(world, rank, collective=collective)
     for r in range(rounds):
         mine = frames[r] if r < len(frames) else torch.zeros(shape, dtype=dtype, device=device)
         g.start(mine)
