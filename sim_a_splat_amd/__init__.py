@@ -14,6 +14,9 @@ _LAZY = {
     "GaussianSplat": ("gaussian_splat", "GaussianSplat"),
     "SplatModel": ("gaussian_splat", "SplatModel"),
     "SplatScene": ("scene", "SplatScene"),
+    "SplatHandler": ("handler", "SplatHandler"),
+    "SplatEnvWrapper": ("env_wrapper", "SplatEnvWrapper"),
+    "SplatVecEnv": ("vec_env", "SplatVecEnv"),
 }
 
 

@@ -174,6 +174,28 @@ class SplatHandler:
             if lock is not None:
                 lock.release()
 
+    def link_pose_rows(self, msg) -> Tuple[np.ndarray, np.ndarray]:
+        """The pose rows ``draw_handler(msg)`` would give this handler's link groups, WITHOUT touching the scene:
+        ``(group indices [k], rows [k,12] float32)``.  Vectorised envs share one scene and keep a pose set per env
+        (``SplatVecEnv``); the rows are the library's context-free ``sas_link_group_poses`` (float64 in C, the
+        arithmetic of splat_handler.py:265-288), the same bits ``sas_set_link_poses`` writes."""
+        from . import _capi
+        rn, rbt = msg.robot_num, self.rbt_idx
+        idxs = [idx for idx in range(msg.num_links) if rn[idx] == rbt][:len(self.fk)]
+        k = min(len(idxs), 7, len(self.splat_links_handler))
+        groups = np.array([h.index for h in self.splat_links_handler[:k]], dtype=np.int64)
+        rows = np.zeros((k, 12), np.float32)
+        if k == 0:
+            return groups, rows
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        q, p = c([msg.quaternion[i] for i in idxs[:k]]), c([msg.position[i] for i in idxs[:k]])
+        Ri, ti, Rfk, tfk, weld = c(self.Ri), c(self.ti), c(self._fkR[:k]), c(self._fkt[:k]), c(self.weld_translation)
+        rc = _capi.lib().sas_link_group_poses(k, float(self.scale_factor), Ri.ctypes.data, ti.ctypes.data, Rfk.ctypes.data, tfk.ctypes.data,
+                                              weld.ctypes.data, q.ctypes.data, p.ctypes.data, rows.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"sas_link_group_poses failed ({rc})")
+        return groups, rows
+
     def get_attached_frame(self, body_name: str, local_frame_pos, msg) -> Tuple[np.ndarray, np.ndarray]:
         """``local_frame_pos``: the camera's ``local_frame`` (SE3-like, as the reference passes it, :316-319) or
         just its translation; only the translation is used -- added in world axes, the reference's behaviour."""

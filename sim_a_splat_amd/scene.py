@@ -223,6 +223,21 @@ class SplatScene:
             # land in pinned host memory on the frames' own streams (sas_render_batch_host): no second round trip
             return self._raster.render_cameras_host(qp[0], qp[1, :, :3], f, int(width), int(height), self.background).numpy()
 
+    def get_renders_posed(self, height: int, width: int, cam_poses, pose_sets, pose_set, fov: Optional[float] = None,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8 [C,H,W,3] (pinned host tensor) for C same-sized cameras of SEVERAL envs in one call: view v is rendered
+        with the group poses ``pose_sets[pose_set[v]]`` ([S,G,12] float32; vectorised envs, sas_render_batch_host_posed)
+        instead of the scene's current ones; ``out`` supplies the tensor."""
+        f = self.camera.fov if fov is None else float(fov)
+        C = len(cam_poses)
+        q, p = np.empty((C, 4), np.float64), np.empty((C, 3), np.float64)
+        for c, (w, x) in enumerate(cam_poses):
+            q[c], p[c] = w, x
+        V, K = self._views_and_Ks(int(height), int(width), q, p, f)
+        with self.lock:
+            self._sync()
+            return self._raster.render_batch_host(V, K, int(width), int(height), self.background, out=out, pose_sets=pose_sets, pose_set=pose_set)
+
     def attached_frame(self, q_link, p_link, local_xyz, owner=None):
         """(wxyz, xyz) of a camera riding on a link, with the similarity of ``owner``'s ``set_link_constants`` (sas_link_attached_frame)."""
         with self.lock:
