@@ -609,6 +609,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     bool have = false;
+#ifdef SAS_TUNE_STATS
+    unsigned dbg_rx = 0u;
+#endif
     const float sE5 = vgpr_const(0x3aafa464u);   // leading exp coefficient
     // only issues the loads: nothing here may depend on their results
     auto fetch = [&](int at) {
@@ -620,6 +623,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             ra = f.rec[3 * id + 0];
             rb = f.rec[3 * id + 1];
             rc = f.rec[3 * id + 2];
+#ifdef SAS_TUNE_STATS
+            dbg_rx = f.info[id].w;
+#endif
         }
     };
     if (count > 0) fetch(0);
@@ -656,6 +662,21 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #ifdef SAS_TUNE_STATS
         DBG_ADD(12, __popcll(__ballot(have && ment == 0u)));
         DBG_ADD(13, __popcll(__ballot(have)));
+        {   // how many queued (entry, block) pairs would the splat's own bounding box (its radii) remove?
+            unsigned keep = 0u;
+            if (have) {
+                const float rx = (float)(int)dbg_rx, ry = (float)__float_as_int(rc.w);
+                for (int b = 0; b < 16; ++b) {
+                    const float x0 = (float)(tx * SAS_TILE + 4 * (b & 3)) + 0.5f, y0 = (float)(ty * SAS_TILE + 4 * (b >> 2)) + 0.5f;
+                    const bool out = x0 > ra.x + rx || x0 + 3.0f < ra.x - rx || y0 > ra.y + ry || y0 + 3.0f < ra.y - ry;
+                    if (!out) keep |= 1u << b;
+                }
+            }
+            unsigned a = __popc(ment), c = __popc(ment & keep);
+            for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d); c += __shfl_xor(c, d); }
+            DBG_ADD(14, a);
+            DBG_ADD(15, c);
+        }
 #endif
         // Contract T6: sigma as a polynomial in the tile-local pixel centre (x, y),
         //   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,

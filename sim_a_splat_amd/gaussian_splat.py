@@ -131,6 +131,25 @@ class _Dataset:
     def __len__(self) -> int:
         return len(self.cameras)
 
+    def get_image_float32(self, image_idx: int) -> torch.Tensor:
+        """The training / eval image ``image_idx`` as float32 ``[H,W,3]`` in 0..1 (nerfstudio's
+        ``InputDataset.get_image_float32``: the file read as uint8, divided by 255, an alpha channel blended onto
+        black... which is what the reference's ``get_images`` collects, nerfstudio_utils.py:101-111).  The images
+        are the capture a run was trained on; the reference's assets do not ship them (only ``transforms.json``
+        names them), so a missing file raises ``FileNotFoundError`` naming the path expected."""
+        f = self._dataparser_outputs.image_filenames[image_idx]
+        if not Path(f).is_file():
+            raise FileNotFoundError(f"{f}: image {image_idx} of the run's dataset is not on disk (the reference's assets ship "
+                                    f"transforms.json and the run, not the captured images)")
+        from PIL import Image
+        img = np.asarray(Image.open(f), dtype=np.uint8)
+        if img.ndim == 2:
+            img = img[:, :, None].repeat(3, axis=2)
+        x = torch.from_numpy(img.astype(np.float32) / 255.0)
+        if x.shape[-1] == 4:
+            x = x[:, :, :3] * x[:, :, 3:4]
+        return x
+
 
 class GaussianSplat:
     """``GaussianSplat(config_path, res_factor, test_mode, dataset_mode, device)`` of the reference
@@ -194,6 +213,10 @@ class GaussianSplat:
 
     def get_poses(self):
         return self.cameras.camera_to_worlds
+
+    def get_images(self):
+        """nerfstudio_utils.py:101-111: every image of the chosen split as float32 [H,W,3] (see ``_Dataset.get_image_float32``)."""
+        return [self.dataset.get_image_float32(image_idx) for image_idx in range(len(self.dataset._dataparser_outputs.image_filenames))]
 
     def get_camera_intrinsics(self) -> Tuple[int, int, torch.Tensor]:
         K = self.cameras[0].get_intrinsics_matrices().squeeze()

@@ -29,3 +29,4 @@ for cfg in [int(a) for a in sys.argv[1:]] or [3]:
     wait_c, loop_c = int(out[6]), int(out[7])
     print(f"  wave cycles inside the trips {loop_c/1e6:.1f} M, waiting at the batch barrier for the slowest wave {wait_c/1e6:.1f} M ({wait_c/max(loop_c,1):.2f} of the trip time)")
     print(f"  staged entries with an empty block mask (reach no 4x4 block of their tile): {int(out[12])} of {int(out[13])} ({int(out[12])/max(int(out[13]),1):.3f})")
+    print(f"  queued (entry, 4x4 block) pairs the splat's own bounding box (mean +- radii) would drop: {int(out[14]) - int(out[15])} of {int(out[14])} ({1 - int(out[15]) / max(int(out[14]), 1):.3f})")

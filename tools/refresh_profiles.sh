@@ -24,6 +24,9 @@ if [ "${1:-}" = "--install" ]; then
   cp $src/timeline_driver_cmd.txt profiles/${tag}_timeline_driver_cmd.txt
   cp $src/env_steps.txt profiles/${tag}_env_steps.txt
   [ -f $src/api_trace.txt ] && cp $src/api_trace.txt profiles/${tag}_gym_step_api_trace.txt
+  [ -f $src/issue_cost.txt ] && cp $src/issue_cost.txt profiles/${tag}_issue_cost_microbench.txt
+  [ -f $src/slot_time.txt ] && cp $src/slot_time.txt profiles/${tag}_tile_slot_time_partition.txt
+  [ -f $src/bounds_quad_tests.log ] && cp $src/bounds_quad_tests.log profiles/${tag}_bounds_build_quad_forced_gpu_tests.log
   [ -f $src/gpu_tests.log ] && cp $src/gpu_tests.log profiles/${tag}_gpu_tests.log
   [ -f $src/bounds_tests.log ] && cp $src/bounds_tests.log profiles/${tag}_bounds_build_gpu_tests.log
   python tools/collect_traffic.py profiles/${tag}_pmc_fetch_size.csv profiles/${tag}_pmc_write_size.csv profiles/hbm_traffic.json > /dev/null
@@ -31,7 +34,7 @@ if [ "${1:-}" = "--install" ]; then
   ls -la profiles
   exit 0
 fi
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
@@ -58,8 +61,15 @@ timeout -k 10 300 python3 tools/config_fps.py 1 2 3 5 > $out/config_fps.txt 2>&1
 timeout -k 10 200 python3 tools/ramp_probe.py > $out/ramp.txt 2>&1
 { timeout -k 10 200 python3 examples/demo_synthetic_env.py; timeout -k 10 200 python3 tools/door_b_breakdown.py; timeout -k 10 300 python3 tools/vec_env_probe.py 1 4 16; } > $out/env_steps.txt 2>&1
 # the issue-rate microbenchmarks are built here from their sources (no binaries in the tree)
-for mb in pk_f32_rate clock_probe; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench/$mb.hip -o /tmp/$mb || exit 1
+for mb in pk_f32_rate clock_probe issue_probe; do
+  /opt/rocm/bin/hipcc -w -O3 --offload-arch=gfx950 tools/microbench/$mb.hip -o /tmp/$mb || exit 1
 done
 { /tmp/pk_f32_rate | head -9; /tmp/clock_probe; } > $out/microbench.txt 2>&1
+/tmp/issue_probe > $out/issue_cost.txt 2>&1
+# where a tile workgroup's time goes (exclusive laps of thread 0: the -DSAS_TUNE_WGTIME build under variants/)
+SAS_LIB_PATH=variants/lib_wgtime.so timeout -k 10 300 python3 tools/wg_time.py 3 > $out/slot_time.txt 2>&1
+# the GPU suite: product library, bounds-checked build, bounds-checked build with the quad layout forced
+timeout -k 10 600 python3 -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1
+SAS_LIB_PATH=variants/lib_bounds.so timeout -k 10 900 python3 -m pytest tests -m gpu -q > $out/bounds_tests.log 2>&1
+SAS_QUAD=1 SAS_LIB_PATH=variants/lib_bounds.so timeout -k 10 900 python3 -m pytest tests -m gpu -q > $out/bounds_quad_tests.log 2>&1
 tail -c 700 $out/bench.json
