@@ -259,6 +259,9 @@ DEV void project_view(const SasCam &c, const float *cov, float op, float x, floa
     g.thr = lnq + 1e-3f;
 }
 
+// a store the projection's tail may read from another XCD (see the hand-off rule in count_tiles)
+DEV void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // per-tile counts of one view: LDS histogram over the workgroup's window, one global atomic per
 // touched tile; then the workgroup's visible count.  Reached by all 256 threads.
 DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, int *s_hist, int *s_nvis)
@@ -313,10 +316,18 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
         if ((threadIdx.x & 63) == 0 && a16) atomicAdd(&s_nvis[1], a16);
     }
     __syncthreads();
-    // (an agent-scope store: written through to where the tail workgroup, possibly on another XCD, reads it)
+    // HAND-OFF RULE (projection workgroups -> the tail, possibly on another XCD, whose L2 is not coherent with this one):
+    // everything the tail reads from other workgroups must be written by an AGENT-scope atomic (performed where all XCDs
+    // see it): the per-tile counts (atomicAdd on tile_count / tile_big), the window-miss counter, and these stores through
+    // agent_store().  A plain store here -- e.g. a vectorised store of counts -- would sit in this XCD's L2 and reach the
+    // tail stale, silently; the bounds build checks the rule's effect (scan_tail: the sum of wg_vis against a counter that
+    // every workgroup also adds its count to atomically).
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&f.wg_vis[blockIdx.x], s_nvis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f.wg_isect16) __hip_atomic_store(&f.wg_isect16[blockIdx.x], s_nvis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        agent_store(&f.wg_vis[blockIdx.x], s_nvis[0]);
+        if (f.wg_isect16) agent_store(&f.wg_isect16[blockIdx.x], s_nvis[1]);
+#ifdef SAS_DEBUG_BOUNDS
+        atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);   // (bounds build only) the same count through a device atomic: the tail compares
+#endif
     }
 }
 
@@ -451,6 +462,13 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
         h[6] = 0u;
         h[7] = 0u;
         f.stats[5] = 0u;
+#ifdef SAS_DEBUG_BOUNDS
+        {   // self-check of the hand-off: what the tail summed from the per-workgroup stores == what the workgroups added atomically
+            const unsigned twin = __hip_atomic_load(&f.stats[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)SAS_IN((long long)nvis_all == (long long)twin ? 0 : -1, 1, 130);
+            f.stats[6] = 0u;
+        }
+#endif
     }
 }
 
