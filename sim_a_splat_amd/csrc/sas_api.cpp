@@ -48,6 +48,8 @@ struct RenderArgs {
 struct Scratch {
     DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, wgbase, tilemax;
     long long cap = 0;
+    long long seg = 0;            // single-pass binning: keys per tile segment (grown when a tile outgrows it)
+    bool seg_too_big = false;     // ... segments for this slot's frames would exceed the memory budget: two-pass binning instead
     bool counters_zero = false;   // the counter block is known to be all zero (SasFrame invariant)
 };
 
@@ -76,6 +78,7 @@ struct Slot {
     SasParams params{};
     bool busy = false, timed = false, timed_tiles = false;
     bool quad = false;   // the frame runs in the quad layout: projected, binned and composited in 8-pixel tiles (prepare_frame)
+    bool direct = false; // single-pass binning (SasFrame::seg > 0): the projection emits the keys, no scatter launch (prepare_frame)
     bool host_direct = false;   // the tile kernel delivers the uint8 frame to pinned host memory itself
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
 };
@@ -118,6 +121,10 @@ struct sas_ctx {
     int pair_views = -1;            // -1: by scene size
     // quad layout (the frame binned in 8-pixel tiles, one workgroup per 8x8 quadrant): -1 = for views of at most
     // quad_max_tiles 16-pixel tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
+    // single-pass binning (fixed-stride tile segments, the projection emits the keys): -1 = whenever the segments fit
+    // direct_budget bytes per slot, 0 = never (SAS_DIRECT=0: the two-pass path of rounds 1-3)
+    int direct_mode = -1;
+    long long direct_budget = 6ll << 30;
     int quad_mode = -1;
     int quad_max_tiles = 640;        // views of frames that share the chip (SAS_ASYNC, batches): beyond, the layout's 4 x workgroups lose
     int quad_max_tiles_solo = 960;   // one blocking view alone on the GPU: its heaviest tile's chain is the frame (tools/quad_threshold.py)
@@ -278,7 +285,8 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.sort_class = (int *)q.tilebuf.p + 3 * ts;
     f.keys = (unsigned long long *)q.keys.p;
     f.sorted_ids = (int *)q.ids.p;
-    f.cap = q.cap;
+    f.seg = sl.direct ? (int)q.seg : 0;
+    f.cap = sl.direct ? (long long)tiles * q.seg : q.cap;
     f.wg_vis = (int *)q.wgvis.p;
     f.wg_isect16 = sl.quad ? (int *)q.wgvis.p + f_wg_stride(c) : nullptr;
     f.tile_max = (unsigned *)q.tilemax.p;
@@ -377,8 +385,25 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     if ((rc = ensure(c, q.wgvis, sizeof(int) * 2 * f_wg_stride(c)))) return rc;   // visible counts | 16-pixel intersections (quad layout)
     if ((rc = ensure(c, q.wgbase, sizeof(int) * SAS_WIN_BINS * (size_t)((n + 255) / 256 + 1)))) return rc;
     if ((rc = ensure(c, q.tilemax, sizeof(unsigned) * (size_t)tiles))) return rc;
-    if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * (size_t)q.cap))) return rc;
-    if ((rc = ensure(c, q.ids, sizeof(int) * (size_t)q.cap))) return rc;
+    // Single-pass binning: every tile owns a segment of q.seg keys.  First guess: 16 x the mean list of a frame with five
+    // intersections per Gaussian, a power of two (config 3: 16 384 keys = 1.6 GB of keys + ids per slot; its longest list
+    // is ~6 k); a frame whose longest list outgrows it is rendered again with larger segments (complete_oldest).
+    sl.direct = c->direct_mode != 0 && !(a.flags & SAS_FULL_SORT) && !q.seg_too_big;
+    if (sl.direct) {
+        if (q.seg == 0) {
+            long long guess = 16 * ((5 * n) / (tiles > 0 ? tiles : 1) + 1);
+            long long s2 = 1024;
+            while (s2 < guess) s2 <<= 1;
+            q.seg = s2;
+        }
+        if ((long long)tiles * q.seg * 12 > c->direct_budget || q.seg > (1ll << 30)) {
+            sl.direct = false;          // pathological concentration (or a huge frame): the two-pass path has no such limit
+            q.seg_too_big = true;
+        }
+    }
+    const size_t n_keys = sl.direct ? (size_t)tiles * (size_t)q.seg : (size_t)q.cap;
+    if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * std::max(n_keys, (size_t)q.cap)))) return rc;
+    if ((rc = ensure(c, q.ids, sizeof(int) * std::max(n_keys, (size_t)q.cap)))) return rc;
     if (c->scene.n_groups > 0 && (rc = ensure(c, sl.poses_dev, sizeof(float) * 12 * 256))) return rc;
 
     SasParams &hp = sl.params;
@@ -439,7 +464,7 @@ int enqueue_frame(sas_ctx *c, Slot &sl, int role = ROLE_SINGLE, Slot *partner = 
         HIP_TRY(c, hipEventRecord(sl.ev[1], st));
         HIP_TRY(c, hipEventRecord(sl.ev[2], st));   // SAS_T_SCAN: the scan is the projection's tail
     }
-    sas_launch_scatter(st, c->scene, cam.tw, f);
+    if (!sl.direct) sas_launch_scatter(st, c->scene, cam.tw, f);   // (single-pass binning: keys and tile order are in place when the projection ends)
     if (timing) HIP_TRY(c, hipEventRecord(sl.ev[3], st));
     if (!timing && order) HIP_TRY(c, hipStreamWaitEvent(st, sl.start, 0));
     if (full) sas_launch_sort(st, c->scene, tiles, f, sl.sort_streams);
@@ -485,6 +510,10 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     hipStream_t st = ld.fs;
     for (int k = 0; k < n; ++k)
         if ((rc = prepare_frame(c, *sl[k], st))) return rc;
+    // one launch, one binning scheme: single-pass only when every view of the group has its segments
+    bool all_direct = true;
+    for (int k = 0; k < n; ++k) all_direct = all_direct && sl[k]->direct;
+    for (int k = 0; k < n; ++k) sl[k]->direct = all_direct;   // (the key buffers hold max(tiles * seg, cap) keys either way)
     const RenderArgs &a = ld.args;
     const int tiles = ld.cam.tw * ld.cam.th;
     SasMulti mf{};
@@ -498,7 +527,7 @@ int enqueue_group(sas_ctx *c, Slot **sl, int n)
     for (int k = 0; k < n; ++k) order = order || sl[k]->args.order_caller;
     if (order) HIP_TRY(c, hipEventRecord(ld.start, a.stream));
     sas_launch_project_multi(st, c->scene, mf);
-    sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);
+    if (!all_direct) sas_launch_scatter_multi(st, c->scene, ld.cam.tw, mf);
     if (order) HIP_TRY(c, hipStreamWaitEvent(st, ld.start, 0));   // outputs are first written by the tile kernel
     const bool ttiles = (a.flags & SAS_TIME_TILES) != 0;
     bool any_fill = false;
@@ -569,7 +598,7 @@ int complete_oldest(sas_ctx *c)
             c->stats[SAS_S_NISECT] = s[3];   // intersections with the contract's 16-pixel tiles ([1]: keys written, at the frame's own binning)
             c->stats[SAS_S_NKEYS] = s[1];
             c->stats[SAS_S_MAX_TILE_LEN] = s[4];
-            c->stats[SAS_S_CAPACITY] = mem[k]->scr.cap;
+            c->stats[SAS_S_CAPACITY] = mem[k]->direct ? (long long)mem[k]->cam.tw * mem[k]->cam.th * mem[k]->scr.seg : mem[k]->scr.cap;   // keys the frame's buffer holds
             c->stats[SAS_S_REGROWS] = c->regrows;
             c->stats[SAS_S_WINDOW_MISSES] = s[5];
             c->stats[SAS_S_FALLBACK_TILES] = s[6];
@@ -606,15 +635,26 @@ int complete_oldest(sas_ctx *c)
         }
         // intersection buffer too small: grow to the measured need (+25 %) and render the frame (group) again,
         // with the poses it was submitted with (the slot's snapshot)
-        long long want = 0;
+        long long want = 0, want_seg = 0;
         for (int k = 0; k < g; ++k) {
             const long long need = (long long)mem[k]->stats_host[1];
             want = std::max(want, need + need / 4 + 1024);
+            if (mem[k]->direct) {   // single-pass binning: the longest list (+25 %), as a power of two
+                const long long longest = (long long)mem[k]->stats_host[4];
+                long long s2 = mem[k]->scr.seg;
+                while (s2 < longest + longest / 4) s2 <<= 1;
+                want_seg = std::max(want_seg, s2);
+            }
         }
-        for (int k = 0; k < g; ++k)
-            if (want > mem[k]->scr.cap) mem[k]->scr.cap = want;
-        for (Slot &o : c->slots)   // the other slots will need it too
-            if (o.scr.cap && o.scr.cap < want && !o.busy) o.scr.cap = want;
+        for (int k = 0; k < g; ++k) {
+            if (mem[k]->direct) { if (want_seg > mem[k]->scr.seg) mem[k]->scr.seg = want_seg; }
+            else if (want > mem[k]->scr.cap) mem[k]->scr.cap = want;
+        }
+        for (Slot &o : c->slots) {   // the other slots will need it too
+            if (o.busy) continue;
+            if (want_seg && o.scr.seg && o.scr.seg < want_seg) o.scr.seg = want_seg;
+            if (!want_seg && o.scr.cap && o.scr.cap < want) o.scr.cap = want;
+        }
         c->regrows++;
         int rc = g > 1 ? enqueue_group(c, mem, g) : enqueue_frame(c, sl);
         if (rc) { mark_dirty(c); return rc; }
@@ -658,6 +698,8 @@ int sas_create(int device, sas_ctx **out)
         if (v >= 1 && v <= SAS_MAX_GROUP) c->group_views = v;
     }
     if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("SAS_DIRECT")) c->direct_mode = atoi(e) != 0 ? -1 : 0;
+    if (const char *e = getenv("SAS_DIRECT_BUDGET_MB")) c->direct_budget = std::max(1ll, atoll(e)) << 20;
     if (const char *e = getenv("SAS_QUAD_TILES")) {
         const int v = atoi(e);
         if (v >= 0) c->quad_max_tiles = c->quad_max_tiles_solo = v;

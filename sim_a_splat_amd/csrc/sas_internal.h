@@ -50,7 +50,14 @@ struct SasScene {
 //                  counted by the tile kernel with a system-scope atomic (rare)
 // INVARIANT: tile_count[] and tile_big[] are all zero between frames -- the tile kernel (k_blend on the full path)
 // clears the counts of the tile it has just rendered, so a frame needs no memset in front of its projection.
-// Binning by RESERVATION: a projection workgroup counts its intersections per tile in an LDS window and adds each
+// SINGLE-PASS BINNING (seg > 0; round 4, the product path): every tile owns a segment of `seg` keys at keys + tile * seg
+// (HBM is plentiful: 1.6 GB per slot at config 3), so a key's place is known the moment its tile's count atomic returns
+// -- the projection emits the keys itself: there is no scatter kernel, no wg_base, no offset scan.  A tile longer than
+// `seg` sets the overflow flag (the projection's tail sees the counts); the frame is then rendered again with larger
+// segments, like a frame that outgrew `cap` on the two-pass path below.
+// TWO-PASS binning (seg == 0: SAS_FULL_SORT frames -- their lists are compact, the parity hooks read them -- and frames whose
+// segments would not fit the memory budget), by RESERVATION:
+// a projection workgroup counts its intersections per tile in an LDS window and adds each
 // window bin to tile_count with ONE returning atomic; what it gets back -- where its run starts inside the tile's
 // segment -- goes to wg_base[workgroup][bin].  k_scatter (same workgroups, same windows) then needs no global atomic
 // and no counting pass: position = tile_offset + wg_base + rank in LDS.  Gaussians outside the window scheme (large
@@ -70,6 +77,7 @@ struct SasFrame {
     unsigned long long *keys;  // [cap]  depth bits << 32 | storage slot
     int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
+    int seg;                   // > 0: single-pass binning, tile t's keys (and ids) live at [t * seg, t * seg + count); cap = tiles * seg
     unsigned *stats;           // [8] device counters
     unsigned *tickets;         // [65 * 32]
     unsigned *stats_host;      // [8] pinned

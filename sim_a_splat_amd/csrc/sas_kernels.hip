@@ -264,9 +264,11 @@ DEV void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED,
 
 // per-tile counts of one view: LDS histogram over the workgroup's window, one global atomic per
 // touched tile; then the workgroup's visible count.  Reached by all 256 threads.
-DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, int *s_hist, int *s_nvis)
+DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot, int *s_win, int *s_hist, int *s_base, int *s_nvis)
 {
     const bool vis = g.vis;
+    const int seg = f.seg;   // (uniform) > 0: single-pass binning -- this workgroup EMITS its keys as well
+    const unsigned long long key = ((unsigned long long)__float_as_uint(g.z) << 32) | (unsigned long long)slot;
     const int x0 = g.x0, x1 = g.x1, y0 = g.y0, y1 = g.y1;
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
@@ -292,17 +294,46 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
             for (unsigned b = tid; b < (unsigned)w.area; b += 256u) {
                 const int cnt = s_hist[b];
                 const int tile = (w.Y0 + (int)row) * tw + w.X0 + (int)col;
-                wb[b] = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
+                const int base = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
+                if (seg > 0) {   // where the workgroup's run starts inside the tile's segment stays in LDS; the bin becomes its rank counter
+                    s_base[b] = base;
+                    s_hist[b] = 0;
+                } else {
+                    wb[b] = base;
+                }
                 row += drow;
                 col += dcol;
                 if (col >= ww) { col -= ww; ++row; }
             }
         }
+        if (seg > 0) {
+            // single-pass binning: position = tile segment + the run's start + the key's rank inside the run (LDS atomic)
+            __syncthreads();
+            if (in_win)
+#pragma unroll 1
+                for (int ty = y0; ty < y1; ++ty)
+#pragma unroll 1
+                    for (int tx = x0; tx < x1; ++tx) {
+                        const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                        if (!SAS_IN(b, kHistBins, 117)) continue;
+                        const int pos = s_base[b] + atomicAdd(&s_hist[b], 1);
+                        // pos >= seg: the tile has outgrown its segment (the tail reports it; the frame is rendered again)
+                        if (pos < seg && SAS_IN((long long)(ty * tw + tx) * seg + pos, f.cap, 118)) f.keys[(long long)(ty * tw + tx) * seg + pos] = key;
+                    }
+        }
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
-    for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
-                  [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
+    if (seg > 0) {   // rectangles outside the window scheme: one returning atomic per intersection, the key goes where it points
+        for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, (unsigned)key, (unsigned)(key >> 32), [&](int tile, unsigned lo, unsigned hi) {
+            if (!SAS_IN(tile, f.n_tiles, 103)) return;
+            const int pos = atomicAdd(&f.tile_count[tile], 1);
+            if (pos < seg && SAS_IN((long long)tile * seg + pos, f.cap, 119)) f.keys[(long long)tile * seg + pos] = ((unsigned long long)hi << 32) | lo;
+        });
+    } else {
+        for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
+                      [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
+    }
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); the projection's tail adds the per-workgroup counts up
     if (threadIdx.x == 0) { s_nvis[0] = 0; s_nvis[1] = 0; }
@@ -344,7 +375,7 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, int *s_win, i
 // workgroups of k_scatter, off this critical path.
 DEV int len_class(int v) { return v ? min(15, 32 - __clz(v)) : 0; }
 
-DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
+DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
 {
     const SasFrame &f = *fp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -438,6 +469,54 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
         s_w[tid] = sum;
     }
     __syncthreads();
+    if (f.seg > 0) {
+        // ---- phase 3 (single-pass binning: there is no scatter launch whose front workgroups could do it): the tile ORDER.
+        // Position of a tile = its class's start + the tiles of the class counted by lower copies of the class's bin +
+        // its rank among the tiles this copy counted (a second round of LDS atomics on fresh counters: the order inside a
+        // class is free).  The counts are read a third time (L2 hits).
+        int *s_off = lds + 16 + 512, *s_rank = s_off + 512;
+        {   // per (class, copy): exclusive prefix over the class's 32 copies + the class's start; two classes per wave
+            const int k = tid >> 5;                       // class entry 0..7 for tid < 256; entries 8..15 in a second round
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int idx = 256 * half + tid;
+                const int v = s_bins[idx];
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 32);
+                    if ((lane & 31) >= d) incl += o;
+                }
+                int cstart = 0;
+                for (int j = 0; j < 8 * half + k; ++j) cstart += s_w[j];   // (s_w[j]: size of class entry j)
+                s_off[idx] = cstart + incl - v;
+                s_rank[idx] = 0;
+            }
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < per; k0 += 16) {
+            int4 c[4], g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = k0 + 4 * j < per;
+                c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+                g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * j, t = t0 + k;
+                if (k >= per || t >= tiles) continue;
+                const int cc[4] = {c[j].x + g[j].x, c[j].y + g[j].y, c[j].z + g[j].z, c[j].w + g[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t + q < tiles) {
+                        const int b = (15 - len_class(cc[q])) * 32 + (lane & 31);
+                        const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
+                        if (SAS_IN(pos, tiles, 105)) f.tile_order[pos] = t + q;
+                    }
+            }
+        }
+    }
     if (tid == 0) {
         int start = 0;
         for (int k = 0; k < 16; ++k) {   // descending classes: entry k = class 15 - k
@@ -455,7 +534,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 640 ints */)
         unsigned *h = f.stats_host;      // the statistics, straight to pinned host memory
         h[0] = (unsigned)nvis_all;
         h[1] = (unsigned)carry;
-        h[2] = (long long)carry > f.cap ? 1u : 0u;
+        h[2] = (f.seg > 0 ? maxlen_all > f.seg : (long long)carry > f.cap) ? 1u : 0u;   // single-pass binning: a tile outgrew its segment
         h[3] = f.wg_isect16 ? (unsigned)n16_all : (unsigned)carry;   // intersections with the contract's 16-pixel tiles
         h[4] = (unsigned)maxlen_all;
         h[5] = f.stats[5];
@@ -495,7 +574,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     const bool in_range = i < s.n;
     ViewGeom g[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { g[v].vis = false; g[v].x0 = g[v].x1 = g[v].y0 = g[v].y1 = 0; }
+    for (int v = 0; v < NV; ++v) { g[v].vis = false; g[v].x0 = g[v].x1 = g[v].y0 = g[v].y1 = 0; g[v].z = 0.0f; }
     if (in_range) {
         // the scene is streamed once per frame: non-temporal loads keep it from evicting the
         // records / keys that the tile kernels (of this and the other in-flight frame) re-read
@@ -633,9 +712,10 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     }
     __shared__ int s_win[4];
     __shared__ int s_hist[kHistBins];
+    __shared__ int s_base[kHistBins];   // single-pass binning: start of the workgroup's run inside each window tile's segment
     __shared__ int s_nvis[2];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], s_win, s_hist, s_nvis);
+    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], (unsigned)i, s_win, s_hist, s_base, s_nvis);
     // ---- the last workgroup to get here scans the counts of the frame(s).
     // Everything the tail reads from other workgroups was written by AGENT-scope atomics (the per-tile counts, the
     // window-miss counter, wg_vis below), which are performed at the point all XCDs share; what remains is ordering:

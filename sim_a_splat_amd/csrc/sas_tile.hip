@@ -1258,9 +1258,15 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         return r;
     };
 
-    const long long beg = f.tile_offset[tile];
-    long long end = f.tile_offset[tile + 1];
-    if (end > f.cap) end = f.cap;
+    long long beg, end;
+    if (f.seg > 0) {   // (uniform) single-pass binning: the tile's own segment, as many keys as were counted (at most the segment)
+        beg = (long long)tile * f.seg;
+        end = beg + min(f.tile_count[tile] + f.tile_big[tile], f.seg);
+    } else {
+        beg = f.tile_offset[tile];
+        end = f.tile_offset[tile + 1];
+        if (end > f.cap) end = f.cap;
+    }
     const int n = (int)(end - beg);
     const unsigned long long *g = f.keys + beg;
     if (n >= 0) PH_LAP(0);   // (n: the dependent loads of the tile's index and its offsets have returned)

@@ -506,13 +506,16 @@ def test_group_pose_updates_between_frames(rasterizer):
         assert np.array_equal(got, ref["rgb"])
 
 
-def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch):
-    """More intersections than the initial buffer holds (max(8 N, 2^20) keys): the frame is detected as
-    overflowed from its stats, the buffer grows to the measured need and the frame is rendered again --
-    for a blocking single view, and for both views of an asynchronous pair."""
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_intersection_buffer_regrows_for_single_views_and_pairs(monkeypatch, direct):
+    """More intersections than the initial buffer holds -- a tile longer than its segment (single-pass binning, the
+    product path: 2 048 keys per tile to start with here) or more keys than max(8 N, 2^20) in all (two-pass binning,
+    SAS_DIRECT=0): the frame is detected as overflowed from its stats, the buffer grows to the measured need and the
+    frame is rendered again -- for a blocking single view, and for both views of an asynchronous pair."""
     import torch
     from sim_a_splat_amd.rasterizer import Rasterizer
     monkeypatch.setenv("SAS_PAIR", "1")
+    monkeypatch.setenv("SAS_DIRECT", direct)
     r = Rasterizer("cuda:0")
     sc = make_scene(30000, seed=444, log_scale_mean=float(np.log(0.12)))
     _upload(r, sc)
@@ -977,3 +980,40 @@ def test_tile_kernel_delivers_complete_tile_frames_to_the_host(monkeypatch, quad
         assert np.array_equal(out[0].numpy(), oracle.render_scene(big, bc, background=BG, want_rgb8=True)["rgb8"])
     finally:
         r.close()
+
+
+def test_single_pass_and_two_pass_binning_render_the_same_frames(monkeypatch):
+    """The product path bins in ONE pass (fixed-stride tile segments, the projection emits the keys, the tile order comes
+    from its tail); SAS_DIRECT=0 keeps the two-pass path of rounds 1-3 (count, scan, scatter), which SAS_FULL_SORT frames and
+    frames whose segments would not fit the memory budget still take.  Same frames, bit for bit, equal to the oracle: a
+    1080p view of 200 k Gaussians, a view pair, a 5-view launch group with link poses, and a frame whose segments exceed a
+    1 MB budget (falls back to two passes by itself)."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    sc = make_scene(200_000, seed=77, log_scale_mean=float(np.log(0.012)))
+    cams = [ring_camera(1920, 1080, 1000.0, yaw_deg=30.0 * k) for k in range(2)]
+    small = make_scene(20_000, seed=78, log_scale_mean=float(np.log(0.03)), n_groups=3)
+    scams = [ring_camera(320, 240, 260.0, yaw_deg=72.0 * k) for k in range(5)]
+    sV, sK = np.stack([c.viewmat for c in scams]), np.stack([c.K for c in scams])
+    ref = oracle.render_scene(sc, cams[0], background=BG)
+    frames = {}
+    for mode, env in (("single-pass", {"SAS_DIRECT": "1"}), ("two-pass", {"SAS_DIRECT": "0"}), ("budget", {"SAS_DIRECT": "1", "SAS_DIRECT_BUDGET_MB": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = Rasterizer("cuda:0")
+        _upload(r, sc)
+        one = r.render(cams[0].viewmat, cams[0].K, 1920, 1080, BG, want=("rgb", "alpha", "depth"), depth_fill_max=True)
+        st = r.stats()
+        assert st["n_isect"] == ref["n_isect"] and st["capacity"] >= st["n_isect"]
+        pair = r.render_batch(np.stack([c.viewmat for c in cams]), np.stack([c.K for c in cams]), 1920, 1080, BG, want=("rgb",))["rgb"]
+        out = [one["rgb"].cpu().numpy(), one["alpha"].cpu().numpy(), one["depth"].cpu().numpy(), pair.cpu().numpy()]
+        _upload(r, small, group_id=small.group_id, n_groups=3)
+        r.set_group_poses(random_group_poses(3, seed=9))
+        out.append(r.render_batch(sV, sK, 320, 240, BG, want=("rgb8",))["rgb8"].cpu().numpy())
+        frames[mode] = out
+        r.close()
+        monkeypatch.delenv("SAS_DIRECT_BUDGET_MB", raising=False)
+    assert np.array_equal(frames["single-pass"][0], ref["rgb"]) and np.array_equal(frames["single-pass"][3][0], ref["rgb"])
+    for mode in ("two-pass", "budget"):
+        for a, b in zip(frames["single-pass"], frames[mode]):
+            assert np.array_equal(a, b), mode
