@@ -54,14 +54,19 @@ typedef enum {
 #define SAS_FULL_SORT 16u     /* order every tile list completely and keep it (sas_read_tile_lists); same image */
 
 /* sas_stage_times slots (milliseconds of the last completed frame rendered with SAS_TIMING).  SAS_T_SCAN reads ~0:
- * the offsets scan is the tail of the projection kernel (its last workgroup), not a launch of its own. */
+ * the offsets scan is the tail of the projection kernel (its last workgroup), not a launch of its own.  SAS_T_SCATTER
+ * reads ~0 as well on the product path (single-pass binning: the projection emits the intersection keys itself into
+ * fixed-stride tile segments); it times k_scatter for SAS_FULL_SORT frames and with SAS_DIRECT=0 in the environment
+ * (two-pass binning: count, scan, scatter), which also serves frames whose segments would exceed SAS_DIRECT_BUDGET_MB
+ * (default 6144 MB per frame in flight). */
 enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path only */,
        SAS_T_BLEND /* k_tile_lazy, or k_blend on the full path */, SAS_T_TAIL /* depth fill */,
        SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame.  SAS_S_NISECT counts Gaussian x 16-pixel-tile intersections
  * (gsplat's isect count) whatever the frame's own binning; SAS_S_NKEYS what the frame actually binned (the same number,
- * except in the quad layout, which bins in 8-pixel tiles); SAS_S_MAX_TILE_LEN is the longest list of the frame's own tiles. */
+ * except in the quad layout, which bins in 8-pixel tiles); SAS_S_MAX_TILE_LEN is the longest list of the frame's own tiles;
+ * SAS_S_CAPACITY the keys the frame's buffer holds (single-pass binning: tiles x segment; two-pass: the compact buffer). */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
        SAS_S_FALLBACK_TILES /* tiles the lazy kernel had to order completely */,

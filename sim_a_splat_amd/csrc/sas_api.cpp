@@ -59,7 +59,7 @@ struct Scratch {
 // A frame writes its output buffers only after everything the caller had enqueued on `stream` at the
 // time of sas_render (its projection and binning, which touch only the scene and the slot's scratch,
 // do not wait for the caller); the caller's stream is made to wait for frame i when it is complete.
-// A frame is: [group poses: one small upload kernel] projection (+ scan in its tail) -> scatter -> tile kernel
+// A frame is: [group poses: one small upload kernel] projection (+ key emit, scan and tile order in its tail) [-> scatter: two-pass binning only] -> tile kernel
 // [-> depth tail] [-> host copy].  Parameters travel in the kernels' argument segments, the counters are left
 // zeroed by the tile kernel, the statistics reach the host through pinned words the projection's tail writes:
 // no memset, no upload and no read-back copy around a frame.
@@ -401,7 +401,16 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
             q.seg_too_big = true;
         }
     }
-    const size_t n_keys = sl.direct ? (size_t)tiles * (size_t)q.seg : (size_t)q.cap;
+    size_t n_keys = sl.direct ? (size_t)tiles * (size_t)q.seg : (size_t)q.cap;
+    if (sl.direct && (ensure(c, q.keys, sizeof(unsigned long long) * std::max(n_keys, (size_t)q.cap)) ||
+                      ensure(c, q.ids, sizeof(int) * std::max(n_keys, (size_t)q.cap)))) {
+        // the segments do not fit this GPU's free memory: not an error, the two-pass path needs 12 bytes per intersection only
+        (void)hipGetLastError();
+        c->err.clear();
+        sl.direct = false;
+        q.seg_too_big = true;
+        n_keys = (size_t)q.cap;
+    }
     if ((rc = ensure(c, q.keys, sizeof(unsigned long long) * std::max(n_keys, (size_t)q.cap)))) return rc;
     if ((rc = ensure(c, q.ids, sizeof(int) * std::max(n_keys, (size_t)q.cap)))) return rc;
     if (c->scene.n_groups > 0 && (rc = ensure(c, sl.poses_dev, sizeof(float) * 12 * 256))) return rc;
