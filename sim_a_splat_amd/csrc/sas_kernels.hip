@@ -386,6 +386,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
     const int t0 = tid * per;
     const int4 *win4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
     const int4 *big4 = reinterpret_cast<const int4 *>(f.tile_big + t0);
+    const bool single_pass = f.seg > 0;   // (uniform)
     s_bins[tid] = 0;
     s_bins[256 + tid] = 0;
     // ---- phase 1: totals (bursts of 16 tiles: 2 x 4 16-byte loads in flight, 32 registers)
@@ -400,7 +401,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
         for (int j = 0; j < 4; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -437,7 +438,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
         for (int j = 0; j < 4; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -448,7 +449,9 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
             const int4 o = make_int4(run, run + cc[0], run + cc[0] + cc[1], run + cc[0] + cc[1] + cc[2]);
             run = o.w + cc[3];
             const int4 cur = make_int4(o.x + cw[0], o.y + cw[1], o.z + cw[2], o.w + cw[3]);
-            if (t + 3 < tiles) {
+            if (single_pass) {
+                // (no offset or cursor tables: tile t's keys start at t * seg)
+            } else if (t + 3 < tiles) {
                 *reinterpret_cast<int4 *>(f.tile_offset + t) = o;
                 *reinterpret_cast<int4 *>(f.tile_cursor + t) = cur;
             } else {
@@ -500,7 +503,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
             for (int j = 0; j < 4; ++j) {
                 const bool in = k0 + 4 * j < per;
                 c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-                g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+                g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -1261,7 +1261,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     long long beg, end;
     if (f.seg > 0) {   // (uniform) single-pass binning: the tile's own segment, as many keys as were counted (at most the segment)
         beg = (long long)tile * f.seg;
-        end = beg + min(f.tile_count[tile] + f.tile_big[tile], f.seg);
+        end = beg + min(f.tile_count[tile], f.seg);   // (tile_big stays zero in this mode)
     } else {
         beg = f.tile_offset[tile];
         end = f.tile_offset[tile + 1];
