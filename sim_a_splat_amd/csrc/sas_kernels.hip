@@ -7,11 +7,15 @@
 //                       SH colour, 48-byte projected record, tile rectangle; per-tile counts through
 //                       an LDS histogram over the workgroup's tile window (one global atomic per
 //                       touched tile)
-//               T5      its LAST workgroup to finish (ticket) scans the counts: tile_offset, scatter
-//                       cursors, tiles ordered by list-length class, statistics straight to pinned host
-//                       memory -- no scan kernel, no memset, no read-back copy around a frame
-//   k_scatter   T3      (depth bits | storage slot) keys into per-tile segments, into the runs the projection
-//                       reserved per (workgroup, tile); its front workgroups put the tiles in launch order
+//               T3      SINGLE-PASS BINNING (round 4, the product path): every tile owns a fixed-stride segment of
+//                       the key buffer, so the returning count atomic IS the place of the workgroup's run: the
+//                       same window pass emits the (depth bits | storage slot) keys (LDS ranks) -- no scatter launch
+//               T5      its LAST workgroup to finish (ticket) scans the counts: tiles ordered by list-length
+//                       class, statistics straight to pinned host memory (two-pass binning: also tile_offset and the
+//                       scatter cursors) -- no scan kernel, no memset, no read-back copy around a frame
+//   k_scatter   T3      two-pass binning only (SAS_FULL_SORT frames, SAS_DIRECT=0, segments over budget): keys into
+//                       compact per-tile segments, into the runs the projection reserved per (workgroup, tile); its
+//                       front workgroups put the tiles in launch order
 //
 // ARITHMETIC CONTRACT: every value that reaches an output is produced by the same
 // sequence of IEEE binary32 operations as oracle/sas_oracle.c -- explicit __builtin_fmaf where
