@@ -73,9 +73,30 @@ fg.start(f32)
 res = fg.finish()
 float_ok = res is not None and torch.equal(res[0], f32)
 
+# ---- SplatVecEnv with its gather forced through RCCL (device payload up, gathered frames back down) ------------------------
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import vec_env_fixture as fx  # noqa: E402
+from sim_a_splat_amd.handler import SplatHandler  # noqa: E402
+from sim_a_splat_amd.vec_env import SplatVecEnv  # noqa: E402
+means, covs, colors, opac, masks, icp, fk = fx.scene_arrays()
+h = SplatHandler.from_arrays(means, covs, colors, opac, masks, icp, fk, device=dev.index)
+E = 3
+plain = SplatVecEnv([fx.FakeEnv(e) for e in range(E)], h, fx.camera_info(), rank=0, world=1)                       # no collective: the reference
+via_rccl = SplatVecEnv([fx.FakeEnv(e) for e in range(E)], h, fx.camera_info(), rank=0, world=1, collective=True)   # gather through nccl
+vec_ok, seen = via_rccl._device_payload, 0
+for step in range(3):
+    acts = [0.1 * step + 0.01 * e for e in range(E)]
+    a = plain.reset(seed=5) if step == 0 else plain.step(acts)[0]
+    b = via_rccl.reset(seed=5) if step == 0 else via_rccl.step(acts)[0]
+    for e in range(E):
+        for c in range(2):
+            vec_ok = vec_ok and bool(np.array_equal(a[e][f"camera_{c}"], b[e][f"camera_{c}"]))
+            seen = max(seen, int(a[e][f"camera_{c}"].max()))
+vec_ok = vec_ok and seen > 0          # (the viewport camera looks at the scene; the link camera may not)
+
 ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else "?"
 print(json.dumps({"backend": dist.get_backend(), "world": world, "rccl_version": ver, "steps": STEPS, "views_per_step": V,
                   "pipeline_bit_equal": bool(pipeline_ok), "gather_frames_bit_equal": bool(helper_ok), "float_frame_bit_equal": bool(float_ok),
-                  "device_tensors": True}))
+                  "vec_env_bit_equal": bool(vec_ok), "device_tensors": True}))
 r.close()
 dist.destroy_process_group()
