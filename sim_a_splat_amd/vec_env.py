@@ -65,6 +65,7 @@ class SplatVecEnv:
         self._collective = (self.world > 1) if collective is None else bool(collective)
         self._via_host = True                                            # frames land in pinned host memory (Door B's uint8 arrays)
         self._msgs: List = [None] * self.E
+        self._pin: Optional[bool] = None
         self._bufs = [self._new_buffer() for _ in range(3)]               # a ring: at most two steps outstanding
         self._pending: Dict[int, Tuple] = {}                              # step index -> what travels beside its frames
         self._gathered: Dict[int, Optional[List[torch.Tensor]]] = {}
@@ -77,11 +78,16 @@ class SplatVecEnv:
 
     # -- buffers -----------------------------------------------------------------------------------------------
     def _new_buffer(self) -> torch.Tensor:
+        """A frame buffer of this rank's envs (pinned: the tile kernel stores the frames into it; torch's caching host
+        allocator hands recently freed blocks back, so a buffer per step costs no allocation in steady state)."""
         shape = (self.per_rank * self.C, self.H, self.W, 3)
+        if self._pin is None:                                             # asked once: torch.cuda.is_available() costs 0.4 ms a call
+            self._pin = bool(torch.cuda.is_available())
         try:
-            return torch.zeros(shape, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            return torch.empty(shape, dtype=torch.uint8, pin_memory=self._pin)
         except RuntimeError:                                              # no HIP runtime (CPU tests)
-            return torch.zeros(shape, dtype=torch.uint8)
+            self._pin = False
+            return torch.empty(shape, dtype=torch.uint8)
 
     def _payload(self, buf: torch.Tensor) -> torch.Tensor:
         # RCCL gathers device tensors: the rank's frames go back up once (6 MB per 8 envs x 2 cameras of 240x320: the
@@ -97,7 +103,11 @@ class SplatVecEnv:
         return rows
 
     def _submit(self, i: int, buf: torch.Tensor) -> None:
-        """Render the rank's envs for step ``i`` into ``buf`` (blocking: the frames are on the host when it returns)."""
+        """Render the rank's envs for step ``i`` (blocking: the frames are on the host when it returns) into a buffer of the
+        step's own -- it takes the ring's place for this step, and the observations handed out are views of it, so nothing
+        is copied and nothing a caller still holds is ever overwritten."""
+        buf = self._new_buffer()
+        self._pipe.bufs[i % len(self._pipe.bufs)] = buf
         msgs = [self._msgs[e] for e in self.mine]
         if msgs:
             pose_sets = np.stack([self._pose_set_of(m) for m in msgs])                     # [E_local, G, 12]
@@ -109,7 +119,7 @@ class SplatVecEnv:
         self._done_steps += 1
 
     def _on_gathered(self, step: int, got) -> None:
-        # (the gather's receive buffers are reused by the next step: keep copies)
+        # (the gather's receive buffers are reused by the next step: the observations are views of copies)
         self._gathered[step] = None if got is None else [g.cpu() if g.is_cuda else g.clone() for g in got]
 
     # -- Gym surface ---------------------------------------------------------------------------------------------
@@ -199,7 +209,7 @@ class SplatVecEnv:
                 for k, e in enumerate(D.shard_views(self.E, r, self.world)):
                     frames_of[e] = got[r][k * self.C:(k + 1) * self.C]
         else:                                                              # a single rank, or a rank that is not the root: its own envs
-            buf = self._bufs[t % R]
+            buf = self._pipe.bufs[t % R]
             for k, e in enumerate(self.mine):
                 frames_of[e] = buf[k * self.C:(k + 1) * self.C]
         all_inner = self._exchange_objects(inner)
@@ -208,7 +218,7 @@ class SplatVecEnv:
             o = dict(all_inner.get(e) or {})
             a = fr.numpy() if isinstance(fr, torch.Tensor) else np.asarray(fr)
             for i in range(self.C):
-                o[f"camera_{i}"] = np.moveaxis(a[i], -1, 0).copy()
+                o[f"camera_{i}"] = a[i].transpose(2, 0, 1)      # np.moveaxis(img, -1, 0), as the reference does: a view
             obs[e] = o
         return obs
 
