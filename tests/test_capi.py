@@ -87,3 +87,19 @@ def test_no_tracked_file_is_a_binary_object():
         if magic[:4] == b"\x7fELF" or magic[:7] == b"!<arch>" or magic[:8] == b"__CLANG_" or ".hipv4-" in rel or ".host-x86" in rel:
             bad.append(rel)
     assert not bad, bad
+
+
+def test_dpp_operands_of_the_quad_layout_respect_the_read_hazard():
+    """The quad layout's compositing rides quad broadcasts on its multiply-adds as DPP operands written in inline asm
+    (csrc/sas_tile.hip, SAS_QFMAC), where hipcc's hazard recogniser does not look: on gfx9 a DPP source register must not
+    have been written by a VALU instruction within the two preceding wait states.  tools/isa_audit.py compiles the kernel
+    to gfx950 assembly (CPU only: hipcc cross-compiles) and checks every DPP instruction of it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", ROOT / "tools" / "isa_audit.py")
+    ia = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ia)
+    lines = ia.kernel_asm("k_tile_lazyILb0ELb0ELb1E", [])
+    loops, per, hazards = ia.audit(lines)
+    n_dpp = sum(1 for l in lines if "_dpp" in l and "quad_perm" in l)
+    assert n_dpp >= 16, n_dpp                      # the sixteen broadcast multiply-adds of a trip are there to be checked
+    assert not hazards, hazards[:5]
