@@ -379,7 +379,7 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot
 // workgroups of k_scatter, off this critical path.
 DEV int len_class(int v) { return v ? min(15, 32 - __clz(v)) : 0; }
 
-DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
+DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
 {
     const SasFrame &f = *fp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -481,47 +481,43 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1552 ints */)
         // Position of a tile = its class's start + the tiles of the class counted by lower copies of the class's bin +
         // its rank among the tiles this copy counted (a second round of LDS atomics on fresh counters: the order inside a
         // class is free).  The counts are read a third time (L2 hits).
-        int *s_off = lds + 16 + 512, *s_rank = s_off + 512;
-        {   // per (class, copy): exclusive prefix over the class's 32 copies + the class's start; two classes per wave
-            const int k = tid >> 5;                       // class entry 0..7 for tid < 256; entries 8..15 in a second round
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int idx = 256 * half + tid;
-                const int v = s_bins[idx];
-                int incl = v;
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    const int o = __shfl_up(incl, d, 32);
-                    if ((lane & 31) >= d) incl += o;
-                }
-                int cstart = 0;
-                for (int j = 0; j < 8 * half + k; ++j) cstart += s_w[j];   // (s_w[j]: size of class entry j)
-                s_off[idx] = cstart + incl - v;
-                s_rank[idx] = 0;
-            }
+        int *s_off = lds + 16 + 512, *s_rank = s_off + 512, *s_cstart = s_rank + 512;
+        if (tid == 0) {   // starts of the 16 classes (s_w[j]: size of class entry j)
+            int start = 0;
+            for (int j = 0; j < 16; ++j) { s_cstart[j] = start; start += s_w[j]; }
         }
         __syncthreads();
-        for (int k0 = 0; k0 < per; k0 += 16) {
-            int4 c[4], g[4];
+        // per (class, copy): exclusive prefix over the class's 32 copies + the class's start; two classes per wave, two rounds
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int idx = 256 * half + tid;
+            const int v = s_bins[idx];
+            int incl = v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = k0 + 4 * j < per;
-                c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-                g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
+            for (int d = 1; d < 32; d <<= 1) {
+                const int o = __shfl_up(incl, d, 32);
+                if ((lane & 31) >= d) incl += o;
             }
+            s_off[idx] = s_cstart[idx >> 5] + incl - v;
+            s_rank[idx] = 0;
+        }
+        __syncthreads();
+        // (four tiles per step, not the 16-tile bursts of phases 1 and 2: this pass runs in single-pass frames, whose counts
+        // are all in tile_count, and its registers are the PROJECTION's registers -- bursts cost k_project<3,1> 11 of them
+        // and two waves per SIMD)
+#pragma unroll 1
+        for (int k = 0; k < per; k += 4) {
+            const int t = t0 + k;
+            if (t >= tiles) break;
+            const int4 c = win4[k >> 2];
+            const int cc[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 4 * j, t = t0 + k;
-                if (k >= per || t >= tiles) continue;
-                const int cc[4] = {c[j].x + g[j].x, c[j].y + g[j].y, c[j].z + g[j].z, c[j].w + g[j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (t + q < tiles) {
-                        const int b = (15 - len_class(cc[q])) * 32 + (lane & 31);
-                        const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
-                        if (SAS_IN(pos, tiles, 105)) f.tile_order[pos] = t + q;
-                    }
-            }
+            for (int q = 0; q < 4; ++q)
+                if (t + q < tiles) {
+                    const int b = (15 - len_class(cc[q])) * 32 + (lane & 31);
+                    const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
+                    if (SAS_IN(pos, tiles, 105)) f.tile_order[pos] = t + q;
+                }
         }
     }
     if (tid == 0) {
@@ -758,6 +754,8 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     }
 }
 
+// (k_project<3,1> takes 81 registers since the tail orders the tiles, five waves per SIMD instead of seven: forcing six or
+// seven -- amdgpu_waves_per_eu, the excess spilling inside the tail -- moved the projection by 1 % and nothing else)
 template <int DEG, int NV>
 __global__ __launch_bounds__(256) void k_project(SasScene s, ProjArgs vs)
 {
