@@ -104,6 +104,14 @@ class StepPipeline:
         self.gathered = 0      # steps whose gather has been started
         self._reading: Optional[int] = None   # step whose gather may still be reading its buffer
 
+    def set_buffer(self, step: int, buf) -> None:
+        """Give step ``step`` a buffer of its own in place of the ring's (called from ``submit``: a caller that hands the
+        frames out without copying them allocates one per step)."""
+        self.bufs[step % len(self.bufs)] = buf
+
+    def buffer_of(self, step: int):
+        return self.bufs[step % len(self.bufs)]
+
     def begin(self) -> None:
         self.base = self._completed()
         self.submitted = self.gathered = 0

@@ -143,6 +143,11 @@ class SplatScene:
             self._raster.set_link_constants(*self._link_consts[owner])
             self._link_owner_applied = owner
 
+    def group_pose_rows(self) -> np.ndarray:
+        """A copy of every group's current pose as float32 rows [G,12] (what goes to the GPU): the base of a per-env pose set."""
+        with self.lock:
+            return self._Rt.reshape(-1, 12).copy()
+
     def set_link_poses(self, q_msg, p_msg, owner=None) -> None:
         """The first k links' message poses -> their groups' poses (sas_set_link_poses: float64 in C, the arithmetic of
         ``poses.link_splat_poses`` + the quaternion round trip of the handles), with ``owner``'s constants; the other

@@ -97,7 +97,7 @@ class SplatVecEnv:
     # -- the per-step work of a rank ------------------------------------------------------------------------------
     def _pose_set_of(self, msg) -> np.ndarray:
         """[G,12] float32: every group's pose for this env's draw message (static groups keep the scene's row)."""
-        rows = self.scene._Rt.reshape(-1, 12).copy()
+        rows = self.scene.group_pose_rows()
         idx, link_rows = self.handler.link_pose_rows(msg)
         rows[idx] = link_rows
         return rows
@@ -107,7 +107,7 @@ class SplatVecEnv:
         step's own -- it takes the ring's place for this step, and the observations handed out are views of it, so nothing
         is copied and nothing a caller still holds is ever overwritten."""
         buf = self._new_buffer()
-        self._pipe.bufs[i % len(self._pipe.bufs)] = buf
+        self._pipe.set_buffer(i, buf)
         msgs = [self._msgs[e] for e in self.mine]
         if msgs:
             pose_sets = np.stack([self._pose_set_of(m) for m in msgs])                     # [E_local, G, 12]
@@ -201,7 +201,6 @@ class SplatVecEnv:
 
     def _assemble(self, t: int, inner) -> List[Optional[Dict[str, np.ndarray]]]:
         """camera_i per env from the gathered frames (rank 0: all envs) or from this rank's own buffer."""
-        R = len(self._bufs)
         frames_of = {}
         got = self._gathered.pop(t, None) if self._collective else None
         if got is not None:                                                # rank 0: rank r's block holds its envs in order
@@ -209,7 +208,7 @@ class SplatVecEnv:
                 for k, e in enumerate(D.shard_views(self.E, r, self.world)):
                     frames_of[e] = got[r][k * self.C:(k + 1) * self.C]
         else:                                                              # a single rank, or a rank that is not the root: its own envs
-            buf = self._pipe.bufs[t % R]
+            buf = self._pipe.buffer_of(t)
             for k, e in enumerate(self.mine):
                 frames_of[e] = buf[k * self.C:(k + 1) * self.C]
         all_inner = self._exchange_objects(inner)
