@@ -125,6 +125,8 @@ struct sas_ctx {
     // direct_budget bytes per slot, 0 = never (SAS_DIRECT=0: the two-pass path of rounds 1-3)
     int direct_mode = -1;
     long long direct_budget = 6ll << 30;
+    // exact tile culling on single-pass frames (sas_kernels.hip: tile_reached); SAS_CULL=0 bins whole rectangles as T3 does
+    int cull_mode = 1;
     int quad_mode = -1;
     int quad_max_tiles = 640;        // views of frames that share the chip (SAS_ASYNC, batches): beyond, the layout's 4 x workgroups lose
     int quad_max_tiles_solo = 960;   // one blocking view alone on the GPU: its heaviest tile's chain is the frame (tools/quad_threshold.py)
@@ -288,7 +290,8 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.seg = sl.direct ? (int)q.seg : 0;
     f.cap = sl.direct ? (long long)tiles * q.seg : q.cap;
     f.wg_vis = (int *)q.wgvis.p;
-    f.wg_isect16 = sl.quad ? (int *)q.wgvis.p + f_wg_stride(c) : nullptr;
+    f.cull = (sl.direct && c->cull_mode != 0) ? 1 : 0;
+    f.wg_isect16 = (sl.quad || f.cull) ? (int *)q.wgvis.p + f_wg_stride(c) : nullptr;   // the lists are not T3's: T3's count is kept beside them
     f.tile_max = (unsigned *)q.tilemax.p;
     f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
     f.group_host = c->scene.n_groups > 0 ? sl.poses_host : nullptr;
@@ -708,6 +711,7 @@ int sas_create(int device, sas_ctx **out)
     }
     if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SAS_DIRECT")) c->direct_mode = atoi(e) != 0 ? -1 : 0;
+    if (const char *e = getenv("SAS_CULL")) c->cull_mode = atoi(e) != 0;
     if (const char *e = getenv("SAS_DIRECT_BUDGET_MB")) c->direct_budget = std::max(1ll, atoll(e)) << 20;
     if (const char *e = getenv("SAS_QUAD_TILES")) {
         const int v = atoi(e);

@@ -78,6 +78,7 @@ struct SasFrame {
     int *sorted_ids;           // [cap]  storage slots, per tile, front to back
     long long cap;
     int seg;                   // > 0: single-pass binning, tile t's keys (and ids) live at [t * seg, t * seg + count); cap = tiles * seg
+    int cull;                  // (single-pass binning only) 1: tiles of its rectangle a Gaussian cannot reach are left out of the lists
     unsigned *stats;           // [8] device counters
     unsigned *tickets;         // [65 * 32]
     unsigned *stats_host;      // [8] pinned

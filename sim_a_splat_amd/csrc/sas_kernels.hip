@@ -154,6 +154,7 @@ static_assert(SAS_TUNE_HIST <= SAS_WIN_BINS, "wg_base holds SAS_WIN_BINS entries
 #define SAS_TUNE_WINRECT 64
 #endif
 constexpr int kHistBins = SAS_TUNE_HIST;      // 8 KiB of LDS
+static_assert(SAS_TUNE_WINRECT <= 64, "count_tiles keeps one mask bit per tile of a window rectangle");
 constexpr int kWinRect = SAS_TUNE_WINRECT;    // largest rectangle (tiles) that takes part in the window
 
 struct Window {
@@ -263,29 +264,124 @@ DEV void project_view(const SasCam &c, const float *cov, float op, float x, floa
     g.thr = lnq + 1e-3f;
 }
 
+// ---- exact tile culling (single-pass binning) --------------------------------------------------------------------
+// T3 bins a Gaussian into every tile of its bounding rectangle; T6 then composites it onto a pixel only where
+// alpha = o exp(-sigma) >= 1/255, i.e. sigma <= ln(255 o).  A tile none of whose pixel centres satisfies that receives
+// nothing from the Gaussian, whatever its place in the list: leaving it out of the list changes no pixel.  A fifth of
+// a 1080p frame's intersections are of that kind (the rectangle's corners).  The test is the minimum of sigma over the
+// tile's box of pixel centres: sigma is a convex quadratic with its minimum (0) at the mean, so over a box that does
+// not contain the mean the minimum lies on the edges facing the mean -- the edge x = (box x nearest the mean), where
+// the best y is -B dx / C clamped to the box, and likewise for y.  Margins: 0.05 (as block_mask16) plus 1e-5 of the
+// terms' magnitudes (170 ulp: the contract's own polynomial about the tile centre rounds terms of that size, and what
+// it decides is the contract) -- a tile is dropped only if the minimum exceeds the threshold by more than both.
+struct CullGeom {
+    float mx, my, ha, b, hc, nba, nbc, lim;
+};
+DEV CullGeom cull_geom(const ViewGeom &g)
+{
+    return CullGeom{g.mx, g.my, 0.5f * g.ca, g.cb, 0.5f * g.ccn, -g.cb / g.ca, -g.cb / g.ccn, g.thr + 0.05f};
+}
+// The test for one row of tiles: what depends on the row alone is taken once (CullRow), a tile then costs some 20
+// instructions.  |B dx dy| <= A dx^2 / 2 + C dy^2 / 2 (the conic is positive definite), so twice the sum of the two
+// square terms bounds the magnitude of all three: the relative margin is taken from that sum.
+struct CullRow {
+    float ly, hy, dyc, c2, t, bdyc;
+};
+DEV CullRow cull_row(const CullGeom &q, int ty, float px)
+{
+    CullRow r;
+    r.ly = ((float)ty * px + 0.5f) - q.my;   // pixel centres of the row, relative to the mean
+    r.hy = r.ly + (px - 1.0f);
+    r.dyc = __builtin_amdgcn_fmed3f(0.0f, r.ly, r.hy);
+    r.c2 = q.hc * r.dyc * r.dyc;
+    r.t = q.nba * r.dyc;
+    r.bdyc = q.b * r.dyc;
+    return r;
+}
+DEV bool tile_reached(const CullGeom &q, const CullRow &r, int tx, float px)
+{
+    const float lx = ((float)tx * px + 0.5f) - q.mx, hx = lx + (px - 1.0f);
+    const float dxc = __builtin_amdgcn_fmed3f(0.0f, lx, hx);
+    const float dys = __builtin_amdgcn_fmed3f(q.nbc * dxc, r.ly, r.hy), dxs = __builtin_amdgcn_fmed3f(r.t, lx, hx);
+    // edge x = dxc, y free:  s1 = the square terms, q1 = sigma
+    const float t1 = q.ha * dxc, t3 = q.hc * dys;
+    const float s1 = fma_(t1, dxc, t3 * dys);
+    const float q1 = fma_(q.b * dxc, dys, s1);
+    const float m1 = fma_(-2e-5f, s1, q1);
+    // edge y = dyc, x free
+    const float s2 = fma_(q.ha * dxs, dxs, r.c2);
+    const float q2 = fma_(r.bdyc, dxs, s2);
+    const float m2 = fma_(-2e-5f, s2, q2);
+    return !(m1 > q.lim && m2 > q.lim);   // (a NaN anywhere keeps the tile)
+}
+DEV bool tile_reached(const CullGeom &q, int tx, int ty, float px) { return tile_reached(q, cull_row(q, ty, px), tx, px); }
+// for_each_tile over the tiles the Gaussian can reach (cull: uniform; off = every tile of the rectangle)
+template <typename F>
+DEV void for_each_reached_tile(bool active, bool cull, const CullGeom &q, float px, int x0, int x1, int y0, int y1, int tw,
+                               unsigned v0, unsigned v1, F emit)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = x1 - x0;
+    const int area = active ? w * (y1 - y0) : 0;
+    if (area > 0 && area <= kSmallRect) {
+#pragma unroll 1
+        for (int ty = y0; ty < y1; ++ty) {
+            const CullRow r = cull_row(q, ty, px);
+#pragma unroll 1
+            for (int tx = x0; tx < x1; ++tx)
+                if (!cull || tile_reached(q, r, tx, px)) emit(ty * tw + tx, v0, v1);
+        }
+    }
+    unsigned long long big = __ballot(area > kSmallRect);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
+        const int bw = __shfl(w, src), ba = __shfl(area, src);
+        const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
+        const CullGeom o{__shfl(q.mx, src), __shfl(q.my, src), __shfl(q.ha, src), __shfl(q.b, src),
+                         __shfl(q.hc, src), __shfl(q.nba, src), __shfl(q.nbc, src), __shfl(q.lim, src)};
+#pragma unroll 1
+        for (int i = lane; i < ba; i += 64) {
+            const int ty = by0 + i / bw, tx = bx0 + i % bw;
+            if (!cull || tile_reached(o, tx, ty, px)) emit(ty * tw + tx, b0, b1);
+        }
+    }
+}
+
 // a store the projection's tail may read from another XCD (see the hand-off rule in count_tiles)
 DEV void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // per-tile counts of one view: LDS histogram over the workgroup's window, one global atomic per
 // touched tile; then the workgroup's visible count.  Reached by all 256 threads.
-DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot, int *s_win, int *s_hist, int *s_base, int *s_nvis)
+DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, unsigned slot, int *s_win, int *s_hist, int *s_base, int *s_nvis)
 {
     const bool vis = g.vis;
     const int seg = f.seg;   // (uniform) > 0: single-pass binning -- this workgroup EMITS its keys as well
+    const bool cull = f.cull != 0;   // (uniform; single-pass frames only) tiles the Gaussian cannot reach are left out: tile_reached
+    const CullGeom cg = cull_geom(g);
+    const float px = (float)tile_px;
     const unsigned long long key = ((unsigned long long)__float_as_uint(g.z) << 32) | (unsigned long long)slot;
     const int x0 = g.x0, x1 = g.x1, y0 = g.y0, y1 = g.y1;
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    unsigned long long reached = 0ull;   // the tiles of the rectangle that were counted (kept for the emit pass)
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
         __syncthreads();
-        if (in_win)
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) {
+        if (in_win) {
+            int k = 0;   // tile k of the rectangle, row by row (at most kWinRect = 64 of them: one mask bit each)
+            for (int ty = y0; ty < y1; ++ty) {
+                const CullRow r = cull_row(cg, ty, px);
+                for (int tx = x0; tx < x1; ++tx, ++k) {
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
+                    if (cull && !tile_reached(cg, r, tx, px)) continue;
+                    reached |= 1ull << k;
                     if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
                 }
+            }
+        }
         __syncthreads();
         // one RETURNING atomic per touched tile: the workgroup's run inside the tile's segment is reserved here, and
         // k_scatter (same workgroup, same window) reads where it starts instead of reserving it itself
@@ -317,9 +413,10 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot
 #pragma unroll 1
                 for (int ty = y0; ty < y1; ++ty)
 #pragma unroll 1
-                    for (int tx = x0; tx < x1; ++tx) {
+                    for (int tx = x0; tx < x1; ++tx, reached >>= 1) {
                         const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                         if (!SAS_IN(b, kHistBins, 117)) continue;
+                        if (!(reached & 1ull)) continue;   // (what the count pass found)
                         const int pos = s_base[b] + atomicAdd(&s_hist[b], 1);
                         // pos >= seg: the tile has outgrown its segment (the tail reports it; the frame is rendered again)
                         if (pos < seg && SAS_IN((long long)(ty * tw + tx) * seg + pos, f.cap, 118)) f.keys[(long long)(ty * tw + tx) * seg + pos] = key;
@@ -329,7 +426,7 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot
         atomicAdd(&f.stats[5], 1u);
     }
     if (seg > 0) {   // rectangles outside the window scheme: one returning atomic per intersection, the key goes where it points
-        for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, (unsigned)key, (unsigned)(key >> 32), [&](int tile, unsigned lo, unsigned hi) {
+        for_each_reached_tile(vis && !(w.fits && in_win), cull, cg, px, x0, x1, y0, y1, tw, (unsigned)key, (unsigned)(key >> 32), [&](int tile, unsigned lo, unsigned hi) {
             if (!SAS_IN(tile, f.n_tiles, 103)) return;
             const int pos = atomicAdd(&f.tile_count[tile], 1);
             if (pos < seg && SAS_IN((long long)tile * seg + pos, f.cap, 119)) f.keys[(long long)tile * seg + pos] = ((unsigned long long)hi << 32) | lo;
@@ -344,8 +441,8 @@ DEV void count_tiles(const SasFrame &f, int tw, const ViewGeom &g, unsigned slot
     __syncthreads();
     const unsigned long long vb = __ballot(vis);
     if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis[0], (int)__popcll(vb));
-    if (f.wg_isect16) {   // (uniform) 8-pixel binning: the frame still reports the intersections with the contract's 16-pixel tiles
-        int a16 = vis ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : 0;
+    if (f.wg_isect16) {   // (uniform) 8-pixel binning, culled lists: the frame still reports the intersections with the contract's 16-pixel tiles
+        int a16 = !vis ? 0 : tile_px == 8 ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : rect_area;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) a16 += __shfl_xor(a16, d);
         if ((threadIdx.x & 63) == 0 && a16) atomicAdd(&s_nvis[1], a16);
@@ -718,7 +815,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     __shared__ int s_base[kHistBins];   // single-pass binning: start of the workgroup's run inside each window tile's segment
     __shared__ int s_nvis[2];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, g[v], (unsigned)i, s_win, s_hist, s_base, s_nvis);
+    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, vs.cam[v].tile_px, g[v], (unsigned)i, s_win, s_hist, s_base, s_nvis);
     // ---- the last workgroup to get here scans the counts of the frame(s).
     // Everything the tail reads from other workgroups was written by AGENT-scope atomics (the per-tile counts, the
     // window-miss counter, wg_vis below), which are performed at the point all XCDs share; what remains is ordering:

@@ -236,7 +236,7 @@ def test_lazy_multi_round_tiles(rasterizer):
     """Long lists of nearly transparent splats: nothing saturates, so the lazy kernel has to walk
     every depth bucket range of every tile (many rounds), still bit-exact."""
     rng = np.random.default_rng(22)
-    sc = make_scene(40000, seed=98, log_scale_mean=float(np.log(0.01)))
+    sc = make_scene(52000, seed=98, log_scale_mean=float(np.log(0.01)))   # (lists beyond 4096 after the exact tile culling too)
     sc.means[:] = rng.uniform(-0.4, 0.4, size=sc.means.shape).astype(np.float32)
     sc.opacities[:] = np.clip(sc.opacities, 0.004, 0.01)
     cam = ring_camera(80, 64, 110.0)
@@ -733,7 +733,7 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
         assert r.stats()["fallback_tiles"] > 0
         # many rounds
         rng = np.random.default_rng(22)
-        sc = make_scene(40000, seed=98, log_scale_mean=float(np.log(0.01)))
+        sc = make_scene(52000, seed=98, log_scale_mean=float(np.log(0.01)))
         sc.means[:] = rng.uniform(-0.4, 0.4, size=sc.means.shape).astype(np.float32)
         sc.opacities[:] = np.clip(sc.opacities, 0.004, 0.01)
         _upload(r, sc)
@@ -752,7 +752,8 @@ def test_both_tile_kernel_layouts(monkeypatch, quad):
         _compare(r, sc, ring_camera(640, 480, 500.0))
         st = r.stats()
         assert st["quad_layout"] == int(quad)
-        assert st["n_keys"] > st["n_isect"] if quad == "1" else st["n_keys"] == st["n_isect"]
+        # (ordinary layout: the lists hold T3's rectangle intersections minus the tiles a Gaussian cannot reach)
+        assert st["n_keys"] > st["n_isect"] if quad == "1" else 0 < st["n_keys"] <= st["n_isect"]
     finally:
         r.close()
 
@@ -1017,3 +1018,49 @@ def test_single_pass_and_two_pass_binning_render_the_same_frames(monkeypatch):
     for mode in ("two-pass", "budget"):
         for a, b in zip(frames["single-pass"], frames[mode]):
             assert np.array_equal(a, b), mode
+
+
+@pytest.mark.parametrize("quad", ["0", "1"])
+def test_exact_tile_culling_changes_no_pixel(monkeypatch, quad):
+    """Single-pass frames leave a Gaussian out of the lists of those tiles of its rectangle in which no pixel centre can
+    get alpha >= 1/255 from it (the minimum of sigma over the tile's pixel centres against ln(255 o), with margins:
+    sas_kernels.hip, tile_reached).  Such an entry composites nothing wherever it stands in its list, so the frame is the
+    same bit for bit -- here against the oracle, whose lists are T3's whole rectangles, and against SAS_CULL=0: config-2-like
+    content, needles (scale ratios up to 1 : 3000, every orientation: the conic's cross term cancels its square terms to
+    a part in 10^6 and more), splats larger than the image, opacities from just above 1/255 to 0.999, a camera inside the
+    cloud; both tile layouts.  n_isect stays T3's count; n_keys is what was binned."""
+    import torch
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_QUAD", quad)
+    rng = np.random.default_rng(2024)
+    scenes = []
+    sc = make_scene(60_000, seed=41, log_scale_mean=float(np.log(0.012)))
+    scenes.append((sc, ring_camera(640, 480, 525.0)))
+    needles = make_scene(30_000, seed=42, log_scale_mean=float(np.log(0.01)))
+    needles.scales[:] = np.exp(rng.uniform(np.log(1e-4), np.log(0.3), size=needles.scales.shape)).astype(np.float32)
+    needles.opacities[:] = rng.choice(np.array([0.004, 0.0045, 0.02, 0.3, 0.9, 0.999], np.float32), size=needles.opacities.shape)
+    scenes.append((needles, ring_camera(333, 251, 300.0, yaw_deg=40.0)))
+    big = make_scene(4_000, seed=43, log_scale_mean=float(np.log(0.4)))
+    big.opacities[:] = np.clip(big.opacities, 0.004, 0.2)
+    scenes.append((big, ring_camera(320, 240, 200.0, yaw_deg=10.0)))
+    inside = make_scene(50_000, seed=44, log_scale_mean=float(np.log(0.02)))
+    cam_in = ring_camera(400, 304, 250.0, radius=0.2)
+    scenes.append((inside, cam_in))
+    keys = {}
+    for cull in ("1", "0"):
+        monkeypatch.setenv("SAS_CULL", cull)
+        r = Rasterizer("cuda:0")
+        try:
+            for i, (sc, cam) in enumerate(scenes):
+                _upload(r, sc)
+                _compare(r, sc, cam, depth_fill=True)
+                st = r.stats()
+                keys[(cull, i)] = (st["n_keys"], st["n_isect"])
+        finally:
+            r.close()
+    for i in range(len(scenes)):
+        on, off = keys[("1", i)], keys[("0", i)]
+        assert on[1] == off[1]                      # T3's count either way
+        assert on[0] < off[0], (i, on, off)         # and shorter lists
+        if quad == "0":
+            assert off[0] == off[1]
