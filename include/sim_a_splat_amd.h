@@ -64,8 +64,9 @@ enum { SAS_T_PROJECT = 0, SAS_T_SCAN, SAS_T_SCATTER, SAS_T_SORT /* full path onl
        SAS_T_TOTAL, SAS_T_COUNT };
 
 /* sas_frame_stats slots (int64) of the last completed frame.  SAS_S_NISECT counts Gaussian x 16-pixel-tile intersections
- * (gsplat's isect count) whatever the frame's own binning; SAS_S_NKEYS what the frame actually binned (the same number,
- * except in the quad layout, which bins in 8-pixel tiles); SAS_S_MAX_TILE_LEN is the longest list of the frame's own tiles;
+ * (gsplat's isect count) whatever the frame's own binning; SAS_S_NKEYS what the frame actually binned (fewer on single-pass
+ * frames, whose lists leave out the tiles of a rectangle the Gaussian cannot reach -- no pixel changes; SAS_CULL=0 bins whole
+ * rectangles -- and more in the quad layout, which bins in 8-pixel tiles); SAS_S_MAX_TILE_LEN is the longest list of the frame's own tiles;
  * SAS_S_CAPACITY the keys the frame's buffer holds (single-pass binning: tiles x segment; two-pass: the compact buffer). */
 enum { SAS_S_NVISIBLE = 0, SAS_S_NISECT, SAS_S_MAX_TILE_LEN, SAS_S_CAPACITY, SAS_S_REGROWS,
        SAS_S_WINDOW_MISSES /* workgroups that binned with per-intersection atomics */,
