@@ -116,6 +116,10 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 // are broadcast while the wave is still convergent (a cross-lane read of an inactive lane
 // returns 0), then handed to emit(tile, v0, v1).  Must be reached by all 64 lanes.
 constexpr int kSmallRect = 8;
+// timing experiments only (-DSAS_TUNE_PABL=mask: 1 no count atomics, 2 no key stores, 4 no LDS atomics, 8 no record stores): wrong frames
+#ifndef SAS_TUNE_PABL
+#define SAS_TUNE_PABL 0
+#endif
 
 template <typename F>
 DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsigned v0, unsigned v1, F emit)
@@ -378,7 +382,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
                     const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                     if (cull && !tile_reached(cg, r, tx, px)) continue;
                     reached |= 1ull << k;
-                    if (SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
+                    if (!(SAS_TUNE_PABL & 4) && SAS_IN(b, kHistBins, 101)) atomicAdd(&s_hist[b], 1);
                 }
             }
         }
@@ -394,7 +398,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
             for (unsigned b = tid; b < (unsigned)w.area; b += 256u) {
                 const int cnt = s_hist[b];
                 const int tile = (w.Y0 + (int)row) * tw + w.X0 + (int)col;
-                const int base = (cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
+                const int base = (!(SAS_TUNE_PABL & 1) && cnt && SAS_IN(tile, f.n_tiles, 102)) ? atomicAdd(&f.tile_count[tile], cnt) : 0;
                 if (seg > 0) {   // where the workgroup's run starts inside the tile's segment stays in LDS; the bin becomes its rank counter
                     s_base[b] = base;
                     s_hist[b] = 0;
@@ -417,9 +421,9 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
                         const int b = (ty - w.Y0) * w.ww + (tx - w.X0);
                         if (!SAS_IN(b, kHistBins, 117)) continue;
                         if (!(reached & 1ull)) continue;   // (what the count pass found)
-                        const int pos = s_base[b] + atomicAdd(&s_hist[b], 1);
+                        const int pos = s_base[b] + ((SAS_TUNE_PABL & 4) ? (int)(threadIdx.x & 63) : atomicAdd(&s_hist[b], 1));
                         // pos >= seg: the tile has outgrown its segment (the tail reports it; the frame is rendered again)
-                        if (pos < seg && SAS_IN((long long)(ty * tw + tx) * seg + pos, f.cap, 118)) f.keys[(long long)(ty * tw + tx) * seg + pos] = key;
+                        if (!(SAS_TUNE_PABL & 2) && pos < seg && SAS_IN((long long)(ty * tw + tx) * seg + pos, f.cap, 118)) f.keys[(long long)(ty * tw + tx) * seg + pos] = key;
                     }
         }
     } else if (threadIdx.x == 0 && w.area > 0) {
@@ -795,6 +799,7 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
                         rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
                     }
                     const SasFrame &f = vs.f[v];
+                    if (SAS_TUNE_PABL & 8) continue;
                     f.rec[3 * i + 0] = make_float4(g[v].mx, g[v].my, g[v].ca, g[v].cb);
                     f.rec[3 * i + 1] = make_float4(g[v].ccn, op, g[v].thr, g[v].z);
                     // radii (parity hook only): x in info.w, y in the record's spare word -- full 32 bits each (a camera
