@@ -50,6 +50,8 @@ struct Scratch {
     long long cap = 0;
     long long seg = 0;            // single-pass binning: keys per tile segment (grown when a tile outgrows it)
     bool seg_too_big = false;     // ... segments for this slot's frames would exceed the memory budget: two-pass binning instead
+    int seg_tiles = -1;           // the tile count and scene size `seg` / `seg_too_big` were established for: another frame size or scene
+    int64_t seg_n = -1;           // sizes the segments afresh (a slot that once met a pathological frame does not stay two-pass for good)
     bool counters_zero = false;   // the counter block is known to be all zero (SasFrame invariant)
 };
 
@@ -391,6 +393,12 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     // Single-pass binning: every tile owns a segment of q.seg keys.  First guess: 16 x the mean list of a frame with five
     // intersections per Gaussian, a power of two (config 3: 16 384 keys = 1.6 GB of keys + ids per slot; its longest list
     // is ~6 k); a frame whose longest list outgrows it is rendered again with larger segments (complete_oldest).
+    if (q.seg_tiles != tiles || q.seg_n != n) {
+        q.seg_too_big = false;
+        if (q.seg && (long long)tiles * q.seg * 12 > c->direct_budget) q.seg = 0;   // learned on smaller frames: guessed anew below
+        q.seg_tiles = tiles;
+        q.seg_n = n;
+    }
     sl.direct = c->direct_mode != 0 && !(a.flags & SAS_FULL_SORT) && !q.seg_too_big;
     if (sl.direct) {
         if (q.seg == 0) {

@@ -1064,3 +1064,27 @@ def test_exact_tile_culling_changes_no_pixel(monkeypatch, quad):
         assert on[0] < off[0], (i, on, off)         # and shorter lists
         if quad == "0":
             assert off[0] == off[1]
+
+
+def test_segment_sizing_follows_the_frame(monkeypatch):
+    """Single-pass binning gives every tile a fixed-stride segment; a frame whose segments would exceed the memory budget
+    (SAS_DIRECT_BUDGET_MB) takes the two-pass path instead.  That verdict belongs to the frame size and the scene it was
+    reached for: the same context goes back to single-pass binning (seen here by the culled lists: n_keys < n_isect) when
+    a smaller scene is uploaded, and both frames equal the oracle."""
+    from sim_a_splat_amd.rasterizer import Rasterizer
+    monkeypatch.setenv("SAS_DIRECT_BUDGET_MB", "128")
+    monkeypatch.setenv("SAS_QUAD", "0")
+    r = Rasterizer("cuda:0")
+    try:
+        big = make_scene(200_000, seed=77, log_scale_mean=float(np.log(0.012)))
+        _upload(r, big)
+        _compare(r, big, ring_camera(1920, 1080, 1000.0))     # 8 160 tiles x 2 048 keys x 12 B = 200 MB: two passes
+        st = r.stats()
+        assert st["n_keys"] == st["n_isect"]
+        small = make_scene(20_000, seed=78, log_scale_mean=float(np.log(0.03)))
+        _upload(r, small)
+        _compare(r, small, ring_camera(640, 480, 500.0))      # 1 200 tiles x 2 048 keys x 12 B = 29 MB: one pass again
+        st = r.stats()
+        assert 0 < st["n_keys"] < st["n_isect"]
+    finally:
+        r.close()
