@@ -858,8 +858,13 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
 
 // (k_project<3,1> takes 81 registers since the tail orders the tiles, five waves per SIMD instead of seven: forcing six or
 // seven -- amdgpu_waves_per_eu, the excess spilling inside the tail -- moved the projection by 1 % and nothing else)
+#ifdef SAS_TUNE_POCC   // A/B builds: waves per SIMD forced for the projection (the pair projection takes 103 registers: four waves)
+#define SAS_PROJECT_ATTRS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAS_TUNE_POCC, SAS_TUNE_POCC)))
+#else
+#define SAS_PROJECT_ATTRS __launch_bounds__(256)
+#endif
 template <int DEG, int NV>
-__global__ __launch_bounds__(256) void k_project(SasScene s, ProjArgs vs)
+__global__ SAS_PROJECT_ATTRS void k_project(SasScene s, ProjArgs vs)
 {
     project_body<DEG, NV>(s, vs, vs.f[0].group_Rt, vs.pose_inline != 0, [&](unsigned g, int k) { return vs.pose_rows[12u * g + (unsigned)k]; });
 }
