@@ -129,6 +129,7 @@ struct sas_ctx {
     long long direct_budget = 6ll << 30;
     // exact tile culling on single-pass frames (sas_kernels.hip: tile_reached); SAS_CULL=0 bins whole rectangles as T3 does
     int cull_mode = 1;
+    int seg_guess_factor = 16;    // first guess of a tile segment = this x the mean list of a frame with five intersections per Gaussian (SAS_SEG_FACTOR)
     int quad_mode = -1;
     int quad_max_tiles = 640;        // views of frames that share the chip (SAS_ASYNC, batches): beyond, the layout's 4 x workgroups lose
     int quad_max_tiles_solo = 960;   // one blocking view alone on the GPU: its heaviest tile's chain is the frame (tools/quad_threshold.py)
@@ -402,7 +403,7 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     sl.direct = c->direct_mode != 0 && !(a.flags & SAS_FULL_SORT) && !q.seg_too_big;
     if (sl.direct) {
         if (q.seg == 0) {
-            long long guess = 16 * ((5 * n) / (tiles > 0 ? tiles : 1) + 1);
+            long long guess = c->seg_guess_factor * ((5 * n) / (tiles > 0 ? tiles : 1) + 1);
             long long s2 = 1024;
             while (s2 < guess) s2 <<= 1;
             q.seg = s2;
@@ -720,6 +721,7 @@ int sas_create(int device, sas_ctx **out)
     if (const char *e = getenv("SAS_QUAD")) c->quad_mode = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SAS_DIRECT")) c->direct_mode = atoi(e) != 0 ? -1 : 0;
     if (const char *e = getenv("SAS_CULL")) c->cull_mode = atoi(e) != 0;
+    if (const char *e = getenv("SAS_SEG_FACTOR")) c->seg_guess_factor = std::max(1, atoi(e));
     if (const char *e = getenv("SAS_DIRECT_BUDGET_MB")) c->direct_budget = std::max(1ll, atoll(e)) << 20;
     if (const char *e = getenv("SAS_QUAD_TILES")) {
         const int v = atoi(e);
