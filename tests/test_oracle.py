@@ -246,3 +246,53 @@ def test_oracle_on_config3_crop_against_the_float64_twin(golden_dir):
     dd = np.abs(o["depth"][win] - g["depth"]) / np.maximum(g["depth"], 1e-3)
     assert float(np.median(dd)) < 1e-5 and int((dd > 1e-3).sum()) <= 3
     print(f"config 3 crop: {worst} of {g['alpha'].size} pixels beyond 1e-4 against the float64 twin")
+
+
+def test_tile_culling_criterion_drops_only_tiles_no_pixel_of_which_is_reached():
+    """The single-pass projection leaves a Gaussian out of the tiles of its rectangle that `tile_reached` rejects
+    (sas_kernels.hip; tests/tools/tile_cull_model.py restates it in float32 NumPy).  The criterion, checked by brute force in
+    float64 on the oracle's own projection of two scenes (config-2-like content; needles and discs with scale ratios up to
+    1 : 3000 in every orientation, opacities from 0.004 to 0.999): in every rejected tile EVERY pixel centre has
+    sigma > ln(255 o) + 0.04, i.e. alpha = o exp(-sigma) < (1/255) e^-0.04 -- T6's `alpha < 1/255` skip fires on all 256
+    pixels with a margin four orders above the rounding of the contract's float32 sigma, so the entry composites nothing
+    wherever it stands in the list.  And the criterion is worth its instructions: it rejects more than a tenth of the
+    rectangle intersections of the first scene."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+    from tile_cull_model import tile_reached
+    from sim_a_splat_amd.synthetic import make_scene, ring_camera
+    rng = np.random.default_rng(5)
+    plain = make_scene(30_000, seed=41, log_scale_mean=float(np.log(0.012)))
+    needles = make_scene(15_000, seed=42, log_scale_mean=float(np.log(0.01)))
+    needles.scales[:] = np.exp(rng.uniform(np.log(1e-4), np.log(0.3), size=needles.scales.shape)).astype(np.float32)
+    needles.opacities[:] = rng.choice(np.array([0.004, 0.0045, 0.02, 0.3, 0.9, 0.999], np.float32), size=needles.opacities.shape)
+    for sc, cam, min_rate in ((plain, ring_camera(640, 480, 525.0), 0.10), (needles, ring_camera(333, 251, 300.0, yaw_deg=40.0), 0.0)):
+        o = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats,
+                          scales=sc.scales, sh_degree=3, dump=True)
+        idx = np.nonzero((o["radii"] > 0).all(axis=1))[0]
+        mx, my = o["means2d"][idx, 0], o["means2d"][idx, 1]
+        A, B, C = (o["conics"][idx, k] for k in range(3))
+        op = np.asarray(sc.opacities, np.float32).reshape(-1)[idx]
+        thr = np.array([oracle.logf(float(np.float32(255.0) * v)) for v in op], np.float32) + np.float32(1e-3)   # (project_view: lnq + 1e-3)
+        tw, th = (cam.width + 15) // 16, (cam.height + 15) // 16
+        rx, ry = o["radii"][idx, 0].astype(np.float32), o["radii"][idx, 1].astype(np.float32)
+        x0 = np.clip(np.floor((mx - rx) / 16), 0, tw).astype(np.int64); x1 = np.clip(np.ceil((mx + rx) / 16), 0, tw).astype(np.int64)
+        y0 = np.clip(np.floor((my - ry) / 16), 0, th).astype(np.int64); y1 = np.clip(np.ceil((my + ry) / 16), 0, th).astype(np.int64)
+        w, area = x1 - x0, (x1 - x0) * (y1 - y0)
+        assert int(area.sum()) == o["n_isect"]          # T3's rectangles, as the oracle counts them
+        rep = np.repeat(np.arange(len(idx)), area)
+        k = np.arange(int(area.sum())) - (np.cumsum(area) - area)[rep]
+        tx, ty = x0[rep] + k % w[rep], y0[rep] + k // w[rep]
+        keep = tile_reached(mx[rep], my[rep], A[rep], B[rep], C[rep], thr[rep], tx, ty)
+        drop = np.nonzero(~keep)[0]
+        assert len(drop) >= min_rate * len(rep), (len(drop), len(rep))
+        # brute force over the 256 pixel centres of every rejected tile, float64
+        g = rep[drop]
+        px = (tx[drop][:, None] * 16 + np.arange(16)[None, :] + 0.5)[:, None, :]     # [pairs, 1, 16]
+        py = (ty[drop][:, None] * 16 + np.arange(16)[None, :] + 0.5)[:, :, None]     # [pairs, 16, 1]
+        dx, dy = px - mx[g].astype(np.float64)[:, None, None], py - my[g].astype(np.float64)[:, None, None]
+        a64, b64, c64 = (v[g].astype(np.float64)[:, None, None] for v in (A, B, C))
+        sigma = 0.5 * (a64 * dx * dx + c64 * dy * dy) + b64 * dx * dy
+        slack = sigma.reshape(len(drop), -1).min(axis=1) - np.log(255.0 * op[g].astype(np.float64))
+        assert slack.min() > 0.04, slack.min()
