@@ -275,9 +275,10 @@ DEV void project_view(const SasCam &c, const float *cov, float op, float x, floa
 // a 1080p frame's intersections are of that kind (the rectangle's corners).  The test is the minimum of sigma over the
 // tile's box of pixel centres: sigma is a convex quadratic with its minimum (0) at the mean, so over a box that does
 // not contain the mean the minimum lies on the edges facing the mean -- the edge x = (box x nearest the mean), where
-// the best y is -B dx / C clamped to the box, and likewise for y.  Margins: 0.05 (as block_mask16) plus 1e-5 of the
-// terms' magnitudes (170 ulp: the contract's own polynomial about the tile centre rounds terms of that size, and what
-// it decides is the contract) -- a tile is dropped only if the minimum exceeds the threshold by more than both.
+// the best y is -B dx / C clamped to the box, and likewise for y.  Margins: 0.05 (as block_mask16) plus 2e-5 of the
+// two square terms, which bound the terms' magnitudes (340 ulp: the contract's own polynomial about the tile centre
+// rounds terms of that size, and what it decides is the contract) -- a tile is dropped only if the minimum exceeds
+// the threshold by more than both.  tests/tools/tile_cull_model.py restates the test in NumPy for the CPU suite.
 struct CullGeom {
     float mx, my, ha, b, hc, nba, nbc, lim;
 };
