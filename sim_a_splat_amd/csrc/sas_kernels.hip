@@ -116,7 +116,7 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 // are broadcast while the wave is still convergent (a cross-lane read of an inactive lane
 // returns 0), then handed to emit(tile, v0, v1).  Must be reached by all 64 lanes.
 constexpr int kSmallRect = 8;
-// timing experiments only (-DSAS_TUNE_PABL=mask: 1 no count atomics, 2 no key stores, 4 no LDS atomics, 8 no record stores): wrong frames
+// timing experiments only (-DSAS_TUNE_PABL=mask: 1 no count atomics, 2 no key stores, 4 no LDS atomics, 8 no record stores, 16 one tile per Gaussian): wrong frames
 #ifndef SAS_TUNE_PABL
 #define SAS_TUNE_PABL 0
 #endif
@@ -367,7 +367,8 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     const CullGeom cg = cull_geom(g);
     const float px = (float)tile_px;
     const unsigned long long key = ((unsigned long long)__float_as_uint(g.z) << 32) | (unsigned long long)slot;
-    const int x0 = g.x0, x1 = g.x1, y0 = g.y0, y1 = g.y1;
+    const int x0 = g.x0, y0 = g.y0;
+    const int x1 = (SAS_TUNE_PABL & 16) ? min(g.x1, g.x0 + 1) : g.x1, y1 = (SAS_TUNE_PABL & 16) ? min(g.y1, g.y0 + 1) : g.y1;   // (16: one tile per Gaussian)
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
