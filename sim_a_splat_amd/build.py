@@ -19,6 +19,7 @@ LIB = PKG / "libsas_hip.so"
 SOURCES = [CSRC / "sas_kernels.hip", CSRC / "sas_tile.hip", CSRC / "sas_api.cpp"]
 DEPS = SOURCES + [CSRC / "sas_internal.h", CSRC / "sas_device.h", PKG.parent / "include" / "sim_a_splat_amd.h"]
 ARCH = "gfx950"
+OPT_LEVEL = "-O2"
 
 
 def hipcc_path() -> str:
@@ -38,7 +39,10 @@ def build(force: bool = False, verbose: bool = False, out: Path = None, extra_fl
     if out is None and not force and up_to_date():
         return LIB
     LIB_OUT = Path(out) if out is not None else LIB
-    cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
+    # -O2: measured against -O3 on one box, six back-to-back pairs (profiles/r04_ab_compiler_flags.txt): the tile kernel 1 % shorter,
+    # the pair bench +1.4 %, two VGPRs fewer spilled; the frames are the same bits either way (no flag here lets the compiler
+    # re-associate or contract floating point)
+    cmd = [hipcc_path(), OPT_LEVEL, "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
            # the SLP vectorizer pairs scalar f32 ops into v_pk_*_f32 (1.4x the issue cost of a scalar op on
            # gfx950, tools/microbench/pk_f32_rate.hip) plus the moves that assemble their operands: a net

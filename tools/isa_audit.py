@@ -41,7 +41,7 @@ def classify(op):
 
 def kernel_asm(filt, flags, src="sas_tile.hip"):
     tmp = Path(tempfile.mkdtemp(prefix="sas_isa_"))
-    cmd = [build.hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    cmd = [build.hipcc_path(), build.OPT_LEVEL, "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
            "-fno-slp-vectorize", *flags, f"-I{build.PKG.parent / 'include'}", "-c", "-x", "hip", str(build.CSRC / src), "-o", "t.o", "-save-temps"]
     subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, check=True)
     text = next(tmp.glob("*gfx950.s")).read_text().split("\n")

@@ -7,7 +7,7 @@ from sim_a_splat_amd import build
 args = sys.argv[1:]
 flags = args[args.index("--") + 1:] if "--" in args else []
 filt = args[0] if args and args[0] != "--" else ""
-cmd = [build.hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+cmd = [build.hipcc_path(), build.OPT_LEVEL, "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
        "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", *flags, "-x", "hip", *map(str, build.SOURCES), "-o", "/tmp/_res.so"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
