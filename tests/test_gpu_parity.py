@@ -44,6 +44,19 @@ def _compare(r, sc, cam, group_id=None, group_Rt=None, exact=True, depth_fill=Fa
     return got, ref
 
 
+def _check_crop_against_twin(got, cfg, keys=("rgb", "alpha")):
+    """The committed float64-twin window of a BASELINE config (oracle/make_golden.py gen_cfg_crop) against the HIP frame."""
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / f"render_twin_cfg{cfg}_crop.npz")
+    tx0, ty0, tx1, ty1 = [int(v) for v in g["crop_tiles"]]
+    win = (slice(16 * ty0, 16 * ty1), slice(16 * tx0, 16 * tx1))
+    for k in keys:
+        d = np.abs(got[k][win] - g[k]).max(axis=2)
+        assert int((d > TOL).sum()) <= 3, (k, int((d > TOL).sum()), float(d.max()))
+        assert float(d[d <= TOL].max()) <= 5e-5
+        print(f"config {cfg} crop, {k}: {int((d > TOL).sum())} of {d.size} pixels beyond {TOL} against the float64 twin (max {d.max():.1e})")
+
+
 def test_projection_arrays_bit_exact(rasterizer):
     sc = make_scene(5000, seed=21, log_scale_mean=float(np.log(0.03)))
     cam = ring_camera(200, 120, 150.0, yaw_deg=15.0, elev=0.4)
@@ -263,19 +276,11 @@ def test_full_size_config_against_oracle(rasterizer, cfg):
     assert a.min() >= 0.0 and a.max() <= 1.0
     empty = a[..., 0] == 0
     assert empty.any() and np.array_equal(got["rgb"][empty], np.broadcast_to(np.array(BG, np.float32), got["rgb"][empty].shape))
+    # the float64 twin on this config itself (tests/golden/render_twin_cfg{2,3}_crop.npz: 8 x 6 tiles on the densest part of
+    # this view -- config 3: lists of 2 565 .. 5 675 entries): the HIP frame's window within the north_star tolerance of it
+    # on every pixel but the threshold flips (at most 3 of 12 288; tests/test_oracle.py shows what a flip is)
+    _check_crop_against_twin(got, cfg)
     if cfg == 3:
-        # the float64 twin on config 3 itself (tests/golden/render_twin_cfg3_crop.npz: 8 x 6 tiles on the densest part of
-        # this view, lists of 2 565 .. 5 675 entries): the HIP frame's window within the north_star tolerance of it on
-        # every pixel but the threshold flips (at most 3 of 12 288; tests/test_oracle.py shows what a flip is)
-        from conftest import GOLDEN
-        g = np.load(GOLDEN / "render_twin_cfg3_crop.npz")
-        tx0, ty0, tx1, ty1 = [int(v) for v in g["crop_tiles"]]
-        win = (slice(16 * ty0, 16 * ty1), slice(16 * tx0, 16 * tx1))
-        for k in ("rgb", "alpha"):
-            d = np.abs(got[k][win] - g[k]).max(axis=2)
-            assert int((d > TOL).sum()) <= 3, (k, int((d > TOL).sum()), float(d.max()))
-            assert float(d[d <= TOL].max()) <= 5e-5
-            print(f"config 3 crop, {k}: {int((d > TOL).sum())} of {d.size} pixels beyond {TOL} against the float64 twin (max {d.max():.1e})")
         # the bench's step at full size: a view pair through sas_render_batch (paired by default at this
         # scene size); its first view is the frame just checked against the oracle
         import torch
@@ -314,6 +319,8 @@ def test_config5_all_four_views_5m_gaussians(rasterizer):
     for v, cam in enumerate(cams):
         ref = oracle.render_scene(sc, cam, background=BG)
         assert np.array_equal(batch["rgb"][v].cpu().numpy(), ref["rgb"]), v
+    # ... and view 0 against the float64 twin on its densest 6 x 4 tiles (lists of 19 845 .. 28 317 entries)
+    _check_crop_against_twin({"rgb": batch["rgb"][0].cpu().numpy()}, 5, keys=("rgb",))
 
 
 @pytest.mark.parametrize("name", TWIN_CASES)

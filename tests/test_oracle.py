@@ -221,13 +221,16 @@ def test_contract_vs_textbook_at_full_size_differs_only_through_threshold_flips(
     print(f"config {cfg}: {len(out)} of {cam.width * cam.height} pixels beyond 1e-4 (max {d.max():.1e}), {int(flipped.sum())} flips beyond 2e-5")
 
 
-def test_oracle_on_config3_crop_against_the_float64_twin(golden_dir):
-    """The float64 twin speaks at BASELINE config 3 itself: an 8 x 6-tile window on the densest part of view 0 (lists
-    of 2 565 .. 5 675 entries, 99 % of its pixels end on the T' <= 1e-4 stop), rendered by oracle/np_twin.py from the
-    Gaussians whose rectangle touches it (oracle/make_golden.py gen_cfg3_crop).  The C oracle's full frame, cropped:
-    rgb / alpha within 1e-4 of the twin on every pixel but at most 3 (threshold flips: reported), 5e-5 elsewhere."""
+@pytest.mark.parametrize("cfg", [2, 3, 5])
+def test_oracle_on_full_size_crops_against_the_float64_twin(golden_dir, cfg):
+    """The float64 twin speaks at the BASELINE configs themselves: a window of tiles on the densest part of view 0 --
+    config 3: 8 x 6 tiles, lists of 2 565 .. 5 675 entries, 99 % of its pixels end on the T' <= 1e-4 stop; config 2: 8 x 6
+    tiles, lists of 2 039 .. 4 585; config 5 (5 M Gaussians): 6 x 4 tiles, lists of 19 845 .. 28 317 -- rendered by
+    oracle/np_twin.py from the Gaussians whose rectangle touches it (oracle/make_golden.py gen_cfg_crop).  The C oracle's
+    full frame, cropped: rgb / alpha within 1e-4 of the twin on every pixel but at most 3 (threshold flips: reported),
+    5e-5 elsewhere."""
     from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND as BG, config_scene_and_cameras
-    g = np.load(golden_dir / "render_twin_cfg3_crop.npz")
+    g = np.load(golden_dir / f"render_twin_cfg{cfg}_crop.npz")
     sc, cams = config_scene_and_cameras(int(g["config"]))
     cam = cams[int(g["view"])]
     o = oracle.render_scene(sc, cam, background=BG, dump=True)
@@ -245,7 +248,7 @@ def test_oracle_on_config3_crop_against_the_float64_twin(golden_dir):
         assert float(d[d <= 1e-4].max()) <= 5e-5, (k, float(d[d <= 1e-4].max()))
     dd = np.abs(o["depth"][win] - g["depth"]) / np.maximum(g["depth"], 1e-3)
     assert float(np.median(dd)) < 1e-5 and int((dd > 1e-3).sum()) <= 3
-    print(f"config 3 crop: {worst} of {g['alpha'].size} pixels beyond 1e-4 against the float64 twin")
+    print(f"config {cfg} crop: {worst} of {g['alpha'].size} pixels beyond 1e-4 against the float64 twin")
 
 
 def test_tile_culling_criterion_drops_only_tiles_no_pixel_of_which_is_reached():
