@@ -46,7 +46,7 @@ struct RenderArgs {
 
 // Per-frame scratch.  Every slot owns one, so several frames can be on the GPU at the same time.
 struct Scratch {
-    DevBuf rec, info, tilebuf, keys, ids, counters, wgvis, wgbase, tilemax;
+    DevBuf rec, col, info, tilebuf, keys, ids, counters, wgvis, wgbase, tilemax;
     long long cap = 0;
     long long seg = 0;            // single-pass binning: keys per tile segment (grown when a tile outgrows it)
     bool seg_too_big = false;     // ... segments for this slot's frames would exceed the memory budget: two-pass binning instead
@@ -82,6 +82,7 @@ struct Slot {
     bool quad = false;   // the frame runs in the quad layout: projected, binned and composited in 8-pixel tiles (prepare_frame)
     bool direct = false; // single-pass binning (SasFrame::seg > 0): the projection emits the keys, no scatter launch (prepare_frame)
     bool host_direct = false;   // the tile kernel delivers the uint8 frame to pinned host memory itself
+    bool info_kept = false;     // the frame's projection wrote info[] (SasFrame::keep_info): sas_read_projection need not project again
     int group = 1;   // slots of the launch group this slot LEADS (enqueue_group); 0: member of the group led by an earlier slot
 };
 
@@ -99,7 +100,7 @@ struct sas_ctx {
     int device = 0;
     std::string err;
     // scene
-    DevBuf g0, g1, g2, col, perm;
+    DevBuf g0, g1, g2, col, gid8, perm;
     DevBuf host_stage;   // device staging of sas_render_batch_host's uint8 frames
     // answer of the pinned-memory query for the host buffer of the sas_render_batch_host call being served (cleared when
     // the call returns: nothing is remembered across calls)
@@ -267,13 +268,15 @@ void make_cam(const float *V, const float *K, int W, int H, int tile_px, SasCam 
     c.lim_y_neg = fmaf(0.3f, tan_fovy, c.cy / c.fy);
 }
 
-static size_t f_wg_stride(const sas_ctx *c) { return (size_t)((c->scene.n + 255) / 256 + 1); }
+// (a multiple of four ints and four to spare: the projection's tail reads both arrays with 16-byte loads)
+static size_t f_wg_stride(const sas_ctx *c) { return (((size_t)((c->scene.n + 255) / 256) + 3) & ~(size_t)3) + 4; }
 
-SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
+SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles, bool keep_info = false)
 {
     Scratch &q = sl.scr;
     SasFrame f{};
     f.rec = (float4 *)q.rec.p;
+    f.col = (float4 *)q.col.p;
     f.info = (uint4 *)q.info.p;
     // counters block: [tickets][8 device counters, 16 class cursors][tile_count][tile_big]   (left zeroed by every frame)
     f.tickets = (unsigned *)q.counters.p;
@@ -294,6 +297,11 @@ SasFrame frame_of(sas_ctx *c, Slot &sl, int tiles)
     f.cap = sl.direct ? (long long)tiles * q.seg : q.cap;
     f.wg_vis = (int *)q.wgvis.p;
     f.cull = (sl.direct && c->cull_mode != 0) ? 1 : 0;
+#ifdef SAS_TUNE_STATS
+    keep_info = true;   // (the statistics build reads the radii in the tile kernel)
+#endif
+    f.keep_info = (keep_info || !sl.direct) ? 1 : 0;   // two-pass frames: k_scatter reads the rectangles
+    sl.info_kept = f.keep_info != 0;
     f.wg_isect16 = (sl.quad || f.cull) ? (int *)q.wgvis.p + f_wg_stride(c) : nullptr;   // the lists are not T3's: T3's count is kept beside them
     f.tile_max = (unsigned *)q.tilemax.p;
     f.group_Rt = c->scene.n_groups > 0 ? (const float *)sl.poses_dev.p : nullptr;
@@ -376,7 +384,8 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
         if (want < (1ll << 20)) want = 1ll << 20;
         q.cap = want;
     }
-    if ((rc = ensure(c, q.rec, sizeof(float4) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, q.rec, sizeof(float4) * 2 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, q.col, sizeof(float4) * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.tilebuf, sizeof(int) * (3 * sas_tile_stride(tiles) + 16)))) return rc;
     {
@@ -768,11 +777,11 @@ int sas_destroy(sas_ctx *c)
         if (sl.pair_ev) (void)hipEventDestroy(sl.pair_ev);
         for (auto &e : sl.ev)
             if (e) (void)hipEventDestroy(e);
-        for (DevBuf *b : {&sl.scr.rec, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
+        for (DevBuf *b : {&sl.scr.rec, &sl.scr.col, &sl.scr.info, &sl.scr.tilebuf, &sl.scr.keys, &sl.scr.ids, &sl.scr.counters,
                           &sl.scr.wgvis, &sl.scr.wgbase, &sl.scr.tilemax})
             release(*b);
     }
-    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->perm, &c->host_stage}) release(*b);
+    for (DevBuf *b : {&c->g0, &c->g1, &c->g2, &c->col, &c->gid8, &c->perm, &c->host_stage}) release(*b);
     delete c;
     return SAS_OK;
 }
@@ -808,6 +817,7 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     if ((rc = ensure(c, c->g1, sizeof(float4) * np))) return rc;
     if ((rc = ensure(c, c->g2, sizeof(float4) * np))) return rc;
     if ((rc = ensure(c, c->col, sizeof(float4) * np * planes))) return rc;
+    if ((rc = ensure(c, c->gid8, np))) return rc;
 
     c->perm_host.clear();
     if ((rc = ensure(c, c->perm, sizeof(int) * np))) return rc;
@@ -845,7 +855,7 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
                                 (const float *)s_q.p, (const float *)s_s.p, (const float *)s_cov.p,
                                 (const float *)s_op.p, (const float *)s_col.p, coeff_floats, planes,
                                 (const uint8_t *)s_gid.p, (float4 *)c->g0.p, (float4 *)c->g1.p, (float4 *)c->g2.p,
-                                (float4 *)c->col.p);
+                                (float4 *)c->col.p, (uint8_t *)c->gid8.p);
             hipError_t e = hipDeviceSynchronize();
             if (e != hipSuccess) rc = fail(c, SAS_ERR_HIP, "relayout: %s", hipGetErrorString(e));
         }
@@ -858,6 +868,7 @@ int sas_scene_upload(sas_ctx *c, int64_t n, const float *means, const float *qua
     c->scene.g1 = (const float4 *)c->g1.p;
     c->scene.g2 = (const float4 *)c->g2.p;
     c->scene.col = (const float4 *)c->col.p;
+    c->scene.gid8 = (const uint8_t *)c->gid8.p;
     c->scene.perm = (const int *)c->perm.p;
     c->scene.n = n;
     c->scene.n_pad = n_pad;
@@ -1410,29 +1421,41 @@ int sas_read_projection(sas_ctx *c, int32_t *radii, float *means2d, float *depth
         int rc = complete_all(c);
         if (rc) return rc;
     }
-    const Scratch &q = c->slots[c->last_slot].scr;
+    Slot &ls = c->slots[c->last_slot];
     const int64_t n = c->scene.n;
-    std::vector<float> rec((size_t)12 * n);
+    if (!ls.info_kept && n > 0) {
+        // Single-pass product frames do not write info[] (rectangles, radii: nothing on the device reads them).  The hook
+        // projects the slot's frame once more with it -- same camera, same pose snapshot, the slot's own scratch; that
+        // launch bins again, so the slot's counters are cleared in front of its next frame.
+        const int tiles = ls.cam.tw * ls.cam.th;
+        Slot *mem[1] = {&ls};
+        int rcp = enqueue_poses(c, mem, 1, ls.fs, false);   // (a pair's follower never uploaded its own copy of the snapshot)
+        if (rcp) return rcp;
+        sas_launch_project(ls.fs, c->scene, ls.params, frame_of(c, ls, tiles, true));
+        HIP_TRY(c, hipStreamSynchronize(ls.fs));
+        ls.scr.counters_zero = false;
+    }
+    const Scratch &q = ls.scr;
+    std::vector<float> rec((size_t)8 * n), col((size_t)4 * n);
     std::vector<uint32_t> info((size_t)4 * n);
     if (n > 0) {
-        HIP_TRY(c, hipMemcpy(rec.data(), q.rec.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(rec.data(), q.rec.p, sizeof(float) * 8 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(col.data(), q.col.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(info.data(), q.info.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost));
     }
     for (int64_t j = 0; j < n; ++j) {
         const int64_t i = c->perm_host[(size_t)j];   // slot j holds the caller's Gaussian i
-        const uint32_t rr = info[4 * j + 3];
-        const bool vis = rr != 0;
-        const float *r = &rec[12 * j];
-        if (radii) {   // x in info.w, y in the record's spare word: 32 bits each
-            int32_t ry;
-            memcpy(&ry, &r[11], sizeof(ry));
-            radii[2 * i] = vis ? (int32_t)rr : 0;
-            radii[2 * i + 1] = vis ? ry : 0;
+        const uint32_t rx = info[4 * j + 2], ry = info[4 * j + 3];   // radii: 32 bits each
+        const bool vis = rx != 0;
+        const float *r = &rec[8 * j], *cl = &col[4 * j];
+        if (radii) {
+            radii[2 * i] = vis ? (int32_t)rx : 0;
+            radii[2 * i + 1] = vis ? (int32_t)ry : 0;
         }
         if (means2d) { means2d[2 * i] = vis ? r[0] : 0.f; means2d[2 * i + 1] = vis ? r[1] : 0.f; }
         if (depths) depths[i] = vis ? r[7] : 0.f;
         if (conics) { conics[3 * i] = vis ? r[2] : 0.f; conics[3 * i + 1] = vis ? r[3] : 0.f; conics[3 * i + 2] = vis ? r[4] : 0.f; }
-        if (colors) { colors[3 * i] = vis ? r[8] : 0.f; colors[3 * i + 1] = vis ? r[9] : 0.f; colors[3 * i + 2] = vis ? r[10] : 0.f; }
+        if (colors) { colors[3 * i] = vis ? cl[0] : 0.f; colors[3 * i + 1] = vis ? cl[1] : 0.f; colors[3 * i + 2] = vis ? cl[2] : 0.f; }
     }
     return SAS_OK;
 }

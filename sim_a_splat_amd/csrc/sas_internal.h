@@ -27,6 +27,7 @@ struct SasCam {
 //   col[p*n_pad + n] = floats 4p..4p+3 of the Gaussian's flattened [K,3] coefficient block
 struct SasScene {
     const float4 *g0, *g1, *g2, *col;
+    const uint8_t *gid8;    // [n_pad] group id per slot once more, one byte each: the projection's colour role needs only that of g2
     const int *perm;        // [n] slot j holds the caller's Gaussian perm[j] (Hilbert order, by group)
     int64_t n;
     int64_t n_pad;     // plane stride
@@ -36,9 +37,12 @@ struct SasScene {
 };
 
 // Per-frame scratch owned by the context.
-//   rec[3n..3n+2]  projected record of Gaussian n, 48 B:
-//        (mean2d.x, mean2d.y, conic.a, conic.b) (conic.c, opacity, skip_threshold, depth) (r, g, b, radius y as int bits)
-//   info[n]        (x0 | x1<<16, y0 | y1<<16, depth bits, radius x): tile rectangle, 0 if culled
+//   rec[2n..2n+1]  projected record of Gaussian n, 32 B, written by the projection's GEOMETRY role:
+//        (mean2d.x, mean2d.y, conic.a, conic.b) (conic.c, opacity, skip_threshold, depth)
+//   col[n]         (r, g, b, -), 16 B, written by the projection's COLOUR role (round 5: the two roles are different
+//                  workgroups of one launch, so the colour has an array of its own -- every store instruction of either
+//                  role covers whole cache lines)
+//   info[n]        (x0 | x1<<16, y0 | y1<<16, radius x, radius y): tile rectangle and radii (parity hook), 0 if culled
 //   stats          device counters: [5] workgroups whose screen window did not fit the LDS histogram (direct atomics),
 //                  reset by the projection's tail
 //   tickets        [65 * 32] words: 64 sub-tickets (one cache line each) + the master ticket of the projection's
@@ -65,6 +69,7 @@ struct SasScene {
 // through tile_cursor, as before.
 struct SasFrame {
     float4 *rec;
+    float4 *col;
     uint4 *info;
     int *tile_count;   // [tiles] window intersections per tile (+ zero padding the tail's 16-byte loads may touch)
     int *tile_big;     // [tiles] per-intersection counts of Gaussians outside the window scheme (same padding)
@@ -79,6 +84,8 @@ struct SasFrame {
     long long cap;
     int seg;                   // > 0: single-pass binning, tile t's keys (and ids) live at [t * seg, t * seg + count); cap = tiles * seg
     int cull;                  // (single-pass binning only) 1: tiles of its rectangle a Gaussian cannot reach are left out of the lists
+    int keep_info;             // 1: the geometry role writes info[] (two-pass frames: k_scatter reads it; the parity hook; -DSAS_TUNE_STATS builds).
+                               // Single-pass product frames skip it: nothing on the device reads it, 16 B per Gaussian less to write
     unsigned *stats;           // [8] device counters
     unsigned *tickets;         // [65 * 32]
     unsigned *stats_host;      // [8] pinned
@@ -128,6 +135,7 @@ struct SasMulti {
     SasFrame f[SAS_MAX_GROUP];
     SasParams P[SAS_MAX_GROUP];
     int nv;
+    int mix_k;                                  // geometry blocks per 8 leading blocks of the projection launch (set by the launcher)
     int pose_inline;                            // 1: view k's poses are pose_rows + pose_off[k] (set by the launcher)
     int pose_off[SAS_MAX_GROUP];
     float pose_rows[12 * SAS_MULTI_INLINE_ROWS];
@@ -165,7 +173,7 @@ void sas_launch_host_copy(hipStream_t st, const SasHostCopy &h);
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
-                         float4 *col);
+                         float4 *col, uint8_t *gid8);
 // The projection's LAST workgroup to finish also scans the tile counts (offsets, scatter cursors, tile order,
 // statistics to stats_host) and resets the ticket: there is no scan kernel.
 void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams &P, const SasFrame &f);

@@ -23,6 +23,7 @@
 // (hipcc default), polynomial exp/log.  No MFMA: nothing here is a dense contraction.
 #include "sas_device.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #pragma clang fp contract(off)
@@ -33,12 +34,13 @@ namespace {
 __global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, const int *perm, const float *means,
                                                   const float *quats, const float *scales, const float *cov6,
                                                   const float *opac, const float *colors, int coeff_floats, int planes,
-                                                  const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2, float4 *col)
+                                                  const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2, float4 *col, uint8_t *gid8)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;   // slot
     if (j >= n) return;
     const int64_t i = perm[j];                                    // caller's index
     float gbits = __uint_as_float(gid ? (unsigned)gid[i] : 0u);
+    gid8[j] = gid ? gid[i] : (uint8_t)0;
     g0[j] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
     if (quats) {
         g1[j] = make_float4(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]);
@@ -116,9 +118,29 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 // are broadcast while the wave is still convergent (a cross-lane read of an inactive lane
 // returns 0), then handed to emit(tile, v0, v1).  Must be reached by all 64 lanes.
 constexpr int kSmallRect = 8;
-// timing experiments only (-DSAS_TUNE_PABL=mask: 1 no count atomics, 2 no key stores, 4 no LDS atomics, 8 no record stores, 16 one tile per Gaussian): wrong frames
+// timing experiments only (-DSAS_TUNE_PABL=mask: 1 no count atomics, 2 no key stores, 4 no LDS atomics, 8 no record stores, 16 one tile per Gaussian,
+// 32 colour blocks leave at once, 64 geometry blocks leave at once, 128 no binning (geometry = T1 + records + ticket + tail)): wrong frames
 #ifndef SAS_TUNE_PABL
 #define SAS_TUNE_PABL 0
+#endif
+
+#ifdef SAS_TUNE_PTIME
+// A/B builds only (tools/proj_time.py): per geometry workgroup, EXCLUSIVE laps of thread 0's wall time (100 MHz ticks):
+// [0] loads + T1 + record stores issued, [1] window, [2] histogram zero + cull/count pass, [3] count atomics (returning),
+// [4] emit pass, [5] rectangles outside the window, [6] visible counts, [7] wait for the stores' acknowledgements + barrier,
+// [8] ticket, [9] tail; [14] begin, [15] end.  Colour workgroups: g_dbg_pcol[2 wg] begin, [2 wg + 1] end.
+constexpr int kDbgPMax = 8192;
+__device__ unsigned long long g_dbg_plap[16 * kDbgPMax];
+__device__ unsigned long long g_dbg_pcol[2 * kDbgPMax];
+extern "C" int sas_debug_proj_laps(unsigned long long *geo, unsigned long long *col, int n)
+{
+    const size_t m = (size_t)(n < kDbgPMax ? n : kDbgPMax);
+    if (hipMemcpyFromSymbol(geo, HIP_SYMBOL(g_dbg_plap), sizeof(unsigned long long) * 16 * m) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(col, HIP_SYMBOL(g_dbg_pcol), sizeof(unsigned long long) * 2 * m) == hipSuccess ? 0 : -1;
+}
+#define PL_LAP(i) do { if (threadIdx.x == 0 && pl_wg_ < (unsigned)kDbgPMax) { const unsigned long long now_ = wall_clock64(); g_dbg_plap[16 * pl_wg_ + (i)] = now_ - pl_t_; pl_t_ = now_; } } while (0)
+#else
+#define PL_LAP(i) do { } while (0)
 #endif
 
 template <typename F>
@@ -193,18 +215,7 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
     return w;
 }
 
-// ---- k_project: T1 + T2 + tile counts ----------------------------------------------------------
-// NV = 1: one view.  NV = 2: two views of the same scene in one pass (sas_render_batch pairs them):
-// the Gaussian's 236 bytes, its group transform and its 3-D covariance are fetched / computed once,
-// and only the camera-dependent part (projection, SH direction, record, binning) runs per view --
-// the second view's input traffic, 77 % of a projection's HBM bytes, disappears.
-struct ProjArgs {
-    SasCam cam[2];
-    SasFrame f[2];
-    int pose_inline;                             // 1: the group poses are pose_rows (small blocks: no upload kernel)
-    float pose_rows[12 * SAS_PROJ_INLINE_ROWS];
-};
-
+// ---- k_project: T1 + T2 + T3 + T5 ----------------------------------------------------------------
 // camera-dependent results of one Gaussian for one view
 struct ViewGeom {
     bool vis;
@@ -359,8 +370,10 @@ DEV void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED,
 
 // per-tile counts of one view: LDS histogram over the workgroup's window, one global atomic per
 // touched tile; then the workgroup's visible count.  Reached by all 256 threads.
-DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, unsigned slot, int *s_win, int *s_hist, int *s_base, int *s_nvis)
+DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, unsigned slot, unsigned wg /* this workgroup's chunk of 256 Gaussians */, int *s_win, int *s_hist, int *s_base, int *s_nvis, unsigned long long &pl_t_)
 {
+    const unsigned pl_wg_ = wg;
+    (void)pl_wg_;
     const bool vis = g.vis;
     const int seg = f.seg;   // (uniform) > 0: single-pass binning -- this workgroup EMITS its keys as well
     const bool cull = f.cull != 0;   // (uniform; single-pass frames only) tiles the Gaussian cannot reach are left out: tile_reached
@@ -372,6 +385,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    PL_LAP(1);
     unsigned long long reached = 0ull;   // the tiles of the rectangle that were counted (kept for the emit pass)
     if (w.fits) {
         for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
@@ -389,9 +403,10 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
             }
         }
         __syncthreads();
+        PL_LAP(2);
         // one RETURNING atomic per touched tile: the workgroup's run inside the tile's segment is reserved here, and
         // k_scatter (same workgroup, same window) reads where it starts instead of reserving it itself
-        int *wb = f.wg_base + (size_t)blockIdx.x * SAS_WIN_BINS;
+        int *wb = f.wg_base + (size_t)wg * SAS_WIN_BINS;
         {   // bin b = row * ww + col of the window, walked in steps of 256 bins without a division per step
             const unsigned ww = (unsigned)w.ww, tid = threadIdx.x;
             unsigned row = tid / ww, col = tid - row * ww;
@@ -415,6 +430,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
         if (seg > 0) {
             // single-pass binning: position = tile segment + the run's start + the key's rank inside the run (LDS atomic)
             __syncthreads();
+            PL_LAP(3);
             if (in_win)
 #pragma unroll 1
                 for (int ty = y0; ty < y1; ++ty)
@@ -431,6 +447,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     } else if (threadIdx.x == 0 && w.area > 0) {
         atomicAdd(&f.stats[5], 1u);
     }
+    PL_LAP(4);
     if (seg > 0) {   // rectangles outside the window scheme: one returning atomic per intersection, the key goes where it points
         for_each_reached_tile(vis && !(w.fits && in_win), cull, cg, px, x0, x1, y0, y1, tw, (unsigned)key, (unsigned)(key >> 32), [&](int tile, unsigned lo, unsigned hi) {
             if (!SAS_IN(tile, f.n_tiles, 103)) return;
@@ -441,6 +458,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
         for_each_tile(vis && !(w.fits && in_win), x0, x1, y0, y1, tw, 0u, 0u,
                       [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     }
+    PL_LAP(5);
     // visible count: one plain store per workgroup (a same-address atomic per wave would
     // serialise at ~90 atomics/us); the projection's tail adds the per-workgroup counts up
     if (threadIdx.x == 0) { s_nvis[0] = 0; s_nvis[1] = 0; }
@@ -460,13 +478,22 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     // agent_store().  A plain store here -- e.g. a vectorised store of counts -- would sit in this XCD's L2 and reach the
     // tail stale, silently; the bounds build checks the rule's effect (scan_tail: the sum of wg_vis against a counter that
     // every workgroup also adds its count to atomically).
-    if (threadIdx.x == 0) {
-        agent_store(&f.wg_vis[blockIdx.x], s_nvis[0]);
-        if (f.wg_isect16) agent_store(&f.wg_isect16[blockIdx.x], s_nvis[1]);
+    if (threadIdx.x == 0 && seg > 0) {
+        // single-pass frames: the sums ride on the workgroup's ticket line (words 1, 2), where the tail's first wave finds all of them
+        unsigned *tk = f.tickets + 32u * (wg & 63u);
+        if (s_nvis[0]) atomicAdd(&tk[1], (unsigned)s_nvis[0]);
+        if (f.wg_isect16 && s_nvis[1]) atomicAdd(&tk[2], (unsigned)s_nvis[1]);
+#ifdef SAS_DEBUG_BOUNDS
+        atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);
+#endif
+    } else if (threadIdx.x == 0) {
+        agent_store(&f.wg_vis[wg], s_nvis[0]);
+        if (f.wg_isect16) agent_store(&f.wg_isect16[wg], s_nvis[1]);
 #ifdef SAS_DEBUG_BOUNDS
         atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);   // (bounds build only) the same count through a device atomic: the tail compares
 #endif
     }
+    PL_LAP(6);
 }
 
 // ---- the projection's tail (T5): offsets, cursors, list-length classes, statistics -----------------------------------
@@ -482,6 +509,167 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
 // workgroups of k_scatter, off this critical path.
 DEV int len_class(int v) { return v ? min(15, 32 - __clz(v)) : 0; }
 
+// ---- the tail of a single-pass frame (the product path), round 5 ----------------------------------------------------
+// Per-workgroup laps (tools/proj_time.py) showed the tail of rounds 3-4 taking 17-21 us on the launch's critical path, not
+// the ~10 its ablation had suggested: three passes over the counts (each a dependent burst of L2 round trips per thread),
+// sixteen sequential loads per thread for the visible counts, and the chip idle meanwhile.  This form reads every count
+// ONCE, in one volley of coalesced 16-byte loads (thread t takes tiles 4 (t + 256 j): all of a thread's loads are in
+// flight together), keeps a list-length class byte per GROUP of four tiles in LDS (the geometry role's 16 KiB of window
+// bins are free by now: 40 448 groups; larger frames re-read their counts for the second pass), and places the groups from there.
+// lds: 2 * kHistBins ints.
+constexpr int kTailScratch = 16 + 512 + 512 + 512 + 16;   // cross-wave words, class bins, (class, copy) offsets, ranks, class totals
+DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigned long long &pl_t_)
+{
+    (void)pl_wg_;
+    const SasFrame &f = *fp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles = f.n_tiles;
+    int *s_w = lds;              // [16]
+    int *s_bins = lds + 16;      // [16 classes (descending)][32 copies]
+    int *s_off = s_bins + 512, *s_rank = s_off + 512, *s_ctot = s_rank + 512;
+    unsigned char *s_clsb = reinterpret_cast<unsigned char *>(lds + kTailScratch);   // class of group w = tiles 4 w .. 4 w + 3
+    constexpr int kClsGroups = 4 * (2 * kHistBins - kTailScratch);
+    const int words = (tiles + 3) >> 2;       // groups of four tiles = 16-byte words of counts
+    const bool in_lds = words <= kClsGroups;   // (uniform)
+    const int4 *cnt4 = reinterpret_cast<const int4 *>(f.tile_count);   // (zero-padded past its end: sas_count_stride)
+    // ---- the frame's sums of visible Gaussians and of the contract's 16-pixel intersections: every geometry workgroup added
+    //      its own to words 1 and 2 of its ticket line (64 lines: no address takes more than ~60 adds); wave 0 collects
+    //      them -- agent-scope loads, performed where the adds were -- and leaves the lines zeroed for the next frame
+    int nvis = 0, n16 = 0;
+    if (wv == 0) {
+        unsigned *tk = f.tickets + 32u * (unsigned)lane;
+        nvis = (int)__hip_atomic_load(&tk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n16 = (int)__hip_atomic_load(&tk[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk[1] = 0u;
+        tk[2] = 0u;
+    }
+    s_bins[tid] = 0;
+    s_bins[256 + tid] = 0;
+    s_rank[tid] = 0;
+    s_rank[256 + tid] = 0;
+    __syncthreads();
+    PL_LAP(10);
+    // ---- pass A: totals, longest list, class sizes, class bytes.  The unit of the ORDER is a group of four consecutive tiles
+    //      (one 16-byte word of counts; neighbours in a tile row, whose lists are alike), classed by its longest list: a
+    //      quarter of the LDS atomics, class bytes and order stores of a per-tile order, on a path where a lone workgroup
+    //      issues one instruction per ~7 cycles and wave.  Eight 16-byte loads per thread in one volley (8 192 tiles).
+    int total = 0, maxlen = 0;
+#pragma unroll 1
+    for (int w0 = tid; w0 < words; w0 += 8 * 256) {
+        int4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = (w0 + 256 * j < words) ? cnt4[w0 + 256 * j] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = w0 + 256 * j;
+            if (w >= words) break;
+            // (counts past the last tile are zero: the arrays are zero-padded)
+            total += (c[j].x + c[j].y) + (c[j].z + c[j].w);
+            const int gmax = max(max(c[j].x, c[j].y), max(c[j].z, c[j].w));
+            maxlen = max(maxlen, gmax);
+            const int cl = 15 - len_class(gmax);
+            atomicAdd(&s_bins[cl * 32 + (lane & 31)], 1);
+            if (in_lds) s_clsb[w] = (unsigned char)cl;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        total += __shfl_xor(total, d);
+        maxlen = max(maxlen, __shfl_xor(maxlen, d));
+        nvis += __shfl_xor(nvis, d);
+        n16 += __shfl_xor(n16, d);
+    }
+    if (lane == 0) { s_w[wv] = total; s_w[4 + wv] = maxlen; }
+    if (tid == 0) { s_w[8] = nvis; s_w[12] = n16; }
+    __syncthreads();
+    PL_LAP(11);
+    // ---- per (class, copy): inclusive prefix over the class's 32 copies (a half wave each); the class totals
+    int my_incl[2], my_v[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int idx = 256 * half + tid;
+        const int v = s_bins[idx];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int o = __shfl_up(incl, d, 32);
+            if ((lane & 31) >= d) incl += o;
+        }
+        my_incl[half] = incl;
+        my_v[half] = v;
+        if ((lane & 31) == 31) s_ctot[idx >> 5] = incl;
+    }
+    __syncthreads();
+    int cstart[2] = {0, 0};   // where the class of this thread's (class, copy) bin starts in the order: the classes in front of it
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int t = s_ctot[j];
+        if (j < (tid >> 5)) cstart[0] += t;
+        if (j < 8 + (tid >> 5)) cstart[1] += t;
+    }
+    s_off[tid] = cstart[0] + my_incl[0] - my_v[0];
+    s_off[256 + tid] = cstart[1] + my_incl[1] - my_v[1];
+    __syncthreads();
+    PL_LAP(12);
+    // ---- pass B: the group ORDER (longest classes first; the order inside a class is free): position = the (class, copy)
+    //      offset + the group's rank among the groups this copy counted.  tile_order[p] = the p-th GROUP (k_tile_lazy: workgroup
+    //      b renders tile 4 tile_order[b / 4] + b % 4)
+#pragma unroll 4
+    for (int w = tid; w < words; w += 256) {
+        int cl;
+        if (in_lds) {
+            cl = (int)s_clsb[w];
+        } else {
+            const int4 c = cnt4[w];
+            cl = 15 - len_class(max(max(c.x, c.y), max(c.z, c.w)));
+        }
+        const int b = cl * 32 + (lane & 31);
+        const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
+        if (SAS_IN(pos, words, 105)) f.tile_order[pos] = w;
+    }
+    if (tid == 0) {
+        const int carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const int maxlen_all = max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
+        const int nvis_all = s_w[8];
+        const int n16_all = s_w[12];
+        int start = 0;
+        for (int k = 0; k < 16; ++k) {   // descending classes: entry k = class 15 - k
+            f.class_cursor[k] = start;
+            if (k == 3) f.sort_class[1] = start;
+            if (k == 5) f.sort_class[2] = start;
+            start += s_ctot[k];
+        }
+        f.sort_class[0] = 0;
+        f.sort_class[3] = tiles;
+        f.sort_class[4] = 0;
+        f.sort_class[5] = tiles;
+        f.tile_offset[tiles] = carry;
+        unsigned *h = f.stats_host;      // the statistics, straight to pinned host memory
+        h[0] = (unsigned)nvis_all;
+        h[1] = (unsigned)carry;
+        h[2] = maxlen_all > f.seg ? 1u : 0u;   // a tile outgrew its segment
+        h[3] = f.wg_isect16 ? (unsigned)n16_all : (unsigned)carry;   // intersections with the contract's 16-pixel tiles
+        h[4] = (unsigned)maxlen_all;
+        h[5] = f.stats[5];
+        h[6] = 0u;
+        h[7] = 0u;
+        f.stats[5] = 0u;
+#ifdef SAS_DEBUG_BOUNDS
+        {   // self-check of the hand-off: what the tail summed from the workgroups' adds on the ticket lines == what they added to one counter
+            const unsigned twin = __hip_atomic_load(&f.stats[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)SAS_IN((long long)nvis_all == (long long)twin ? 0 : -1, 1, 130);
+            f.stats[6] = 0u;
+        }
+#endif
+    }
+    PL_LAP(13);
+}
+
+// SINGLE: single-pass binning (the product path) -- every count is in tile_count, there are no offset / cursor tables.
+// The tail's registers are the PROJECTION's registers (the kernel's allocation is the maximum over its roles): the
+// single-pass form reads bursts of 16 tiles (4 x 16-byte loads in flight), the two-pass form, which reads two arrays,
+// bursts of 8 -- either way 16 registers of counts, so that the tail stays below the geometry role's own 59-64.
+template <bool SINGLE>
 DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
 {
     const SasFrame &f = *fp;
@@ -493,25 +681,26 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
     const int t0 = tid * per;
     const int4 *win4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
     const int4 *big4 = reinterpret_cast<const int4 *>(f.tile_big + t0);
-    const bool single_pass = f.seg > 0;   // (uniform)
+    constexpr int NB = SINGLE ? 4 : 2;   // 16-byte loads per array and burst
     s_bins[tid] = 0;
     s_bins[256 + tid] = 0;
-    // ---- phase 1: totals (bursts of 16 tiles: 2 x 4 16-byte loads in flight, 32 registers)
+    // ---- phase 1: totals
     int nvis = 0, n16 = 0;
     for (int i = tid; i < f.n_wg; i += 256) nvis += f.wg_vis[i];
     if (f.wg_isect16)
         for (int i = tid; i < f.n_wg; i += 256) n16 += f.wg_isect16[i];
     int total = 0, maxlen = 0;
-    for (int k0 = 0; k0 < per; k0 += 16) {
-        int4 c[4], g[4];
+#pragma unroll 1
+    for (int k0 = 0; k0 < per; k0 += 4 * NB) {
+        int4 c[NB], g[NB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
+            g[j] = (in && !SINGLE) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int sx = c[j].x + g[j].x, sy = c[j].y + g[j].y, sz = c[j].z + g[j].z, sw = c[j].w + g[j].w;
             total += (sx + sy) + (sz + sw);
             maxlen = max(max(maxlen, max(sx, sy)), max(sz, sw));
@@ -538,34 +727,35 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
     const int maxlen_all = max(max(s_w[4], s_w[5]), max(s_w[6], s_w[7]));
     const int nvis_all = s_w[8] + s_w[9] + s_w[10] + s_w[11];
     const int n16_all = s_w[12] + s_w[13] + s_w[14] + s_w[15];
-    // ---- phase 2: offsets, cursors of the `big` entries, class sizes
-    for (int k0 = 0; k0 < per; k0 += 16) {
-        int4 c[4], g[4];
+    // ---- phase 2: class sizes (two-pass binning: also the offsets and the cursors of the `big` entries)
+#pragma unroll 1
+    for (int k0 = 0; k0 < per; k0 += 4 * NB) {
+        int4 c[NB], g[NB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = (in && !single_pass) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
+            g[j] = (in && !SINGLE) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int k = k0 + 4 * j, t = t0 + k;
             if (k >= per || t >= tiles) continue;
-            const int cw[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
             const int cc[4] = {c[j].x + g[j].x, c[j].y + g[j].y, c[j].z + g[j].z, c[j].w + g[j].w};
-            const int4 o = make_int4(run, run + cc[0], run + cc[0] + cc[1], run + cc[0] + cc[1] + cc[2]);
-            run = o.w + cc[3];
-            const int4 cur = make_int4(o.x + cw[0], o.y + cw[1], o.z + cw[2], o.w + cw[3]);
-            if (single_pass) {
-                // (no offset or cursor tables: tile t's keys start at t * seg)
-            } else if (t + 3 < tiles) {
-                *reinterpret_cast<int4 *>(f.tile_offset + t) = o;
-                *reinterpret_cast<int4 *>(f.tile_cursor + t) = cur;
-            } else {
-                const int oo[4] = {o.x, o.y, o.z, o.w}, uu[4] = {cur.x, cur.y, cur.z, cur.w};
+            if constexpr (!SINGLE) {
+                const int cw[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+                const int4 o = make_int4(run, run + cc[0], run + cc[0] + cc[1], run + cc[0] + cc[1] + cc[2]);
+                run = o.w + cc[3];
+                const int4 cur = make_int4(o.x + cw[0], o.y + cw[1], o.z + cw[2], o.w + cw[3]);
+                if (t + 3 < tiles) {
+                    *reinterpret_cast<int4 *>(f.tile_offset + t) = o;
+                    *reinterpret_cast<int4 *>(f.tile_cursor + t) = cur;
+                } else {
+                    const int oo[4] = {o.x, o.y, o.z, o.w}, uu[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (t + q < tiles) { f.tile_offset[t + q] = oo[q]; f.tile_cursor[t + q] = uu[q]; }
+                    for (int q = 0; q < 4; ++q)
+                        if (t + q < tiles) { f.tile_offset[t + q] = oo[q]; f.tile_cursor[t + q] = uu[q]; }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -579,7 +769,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         s_w[tid] = sum;
     }
     __syncthreads();
-    if (f.seg > 0) {
+    if constexpr (SINGLE) {
         // ---- phase 3 (single-pass binning: there is no scatter launch whose front workgroups could do it): the tile ORDER.
         // Position of a tile = its class's start + the tiles of the class counted by lower copies of the class's bin +
         // its rank among the tiles this copy counted (a second round of LDS atomics on fresh counters: the order inside a
@@ -640,7 +830,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         unsigned *h = f.stats_host;      // the statistics, straight to pinned host memory
         h[0] = (unsigned)nvis_all;
         h[1] = (unsigned)carry;
-        h[2] = (f.seg > 0 ? maxlen_all > f.seg : (long long)carry > f.cap) ? 1u : 0u;   // single-pass binning: a tile outgrew its segment
+        h[2] = (SINGLE ? maxlen_all > f.seg : (long long)carry > f.cap) ? 1u : 0u;   // single-pass binning: a tile outgrew its segment
         h[3] = f.wg_isect16 ? (unsigned)n16_all : (unsigned)carry;   // intersections with the contract's 16-pixel tiles
         h[4] = (unsigned)maxlen_all;
         h[5] = f.stats[5];
@@ -657,7 +847,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
     }
 }
 
-// Scene loads.  A view pair streams the scene once, non-temporally, so that it does not evict the records
+// Scene loads.  A view pair streams the colour planes once, non-temporally, so that they do not evict the records
 // and keys the tile kernels re-read (+1 % frames/s).  Single views are submitted up to four deep and
 // their projections overlap: ordinary loads let them share the scene through L2 / the memory-side cache
 // (+3 % frames/s at 1 M Gaussians, +11 % at 5 M over non-temporal loads).
@@ -668,67 +858,96 @@ DEV float4 scene_load(const float4 *p)
     else return *p;
 }
 
-// Group poses reach a lane in one of two ways: from the slot's device block (12 per-lane loads), or -- small pose
-// blocks, `inline_row(g, k)` -- from the launch's ARGUMENT segment: the scene is stored by group, so a wave almost
-// always holds one group; its row is fetched with scalar loads at a uniform index (no upload kernel in front of the
-// projection, no address of the argument struct taken: that would make the compiler copy it to scratch).
-template <int DEG, int NV, typename RowFn>
-DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses /* [n_groups,12] device, or nullptr */,
-                      bool poses_inline, RowFn inline_row)
+// Group pose of this lane's Gaussian.  Poses reach a lane in one of two ways: from the slot's device block (12 per-lane
+// loads), or -- small pose blocks, `inline_row(g, k)` -- from the launch's ARGUMENT segment: the scene is stored by group,
+// so a wave almost always holds one group; its row is fetched with scalar loads at a uniform index (no upload kernel in
+// front of the projection, no address of the argument struct taken: that would make the compiler copy it to scratch).
+// Must be called by the in-range lanes of a wave together.  Returns whether the scene has poses at all.
+template <typename RowFn>
+DEV bool group_pose(unsigned gid, const float *poses, bool poses_inline, RowFn inline_row, float *G)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = i < s.n;
-    ViewGeom g[NV];
+    if (poses_inline) {
+        unsigned long long todo = __ballot(true);
+        while (todo) {
+            const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)todo) - 1);
+            const bool mine = gid == g;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { g[v].vis = false; g[v].x0 = g[v].x1 = g[v].y0 = g[v].y1 = 0; g[v].z = 0.0f; }
-    if (in_range) {
-        // the scene is streamed once per frame: non-temporal loads keep it from evicting the
-        // records / keys that the tile kernels (of this and the other in-flight frame) re-read
-        const float4 a0 = scene_load<NV>(s.g0 + i);
-        const float4 a1 = scene_load<NV>(s.g1 + i);
-        const float4 a2 = scene_load<NV>(s.g2 + i);
+            for (int k = 0; k < 12; ++k) {
+                const float r = inline_row(g, k);   // uniform: scalar load
+                if (mine) G[k] = r;
+            }
+            todo &= ~__ballot(mine);
+        }
+        return true;
+    }
+    if (poses) {
+        const float *Gp = poses + 12 * gid;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) G[k] = Gp[k];
+        return true;
+    }
+    return false;
+}
+
+// ---- the projection, round 5: TWO ROLES IN ONE LAUNCH ----------------------------------------------------------------
+// Rounds 1-4 ran T1, T2 and the binning in one body: every workgroup streamed its 256 Gaussians' 236 bytes, held the 48
+// SH coefficients beside the projected geometry (81-102 registers: four or five waves per SIMD), and then sat through the
+// binning's barriers, atomics and scattered key stores with those registers -- the streaming phase reached 4.4 TB/s and
+// the launch ended on a 10 us single-workgroup tail (the scan of the tile counts) with the chip idle.  Now the launch's
+// workgroups have one of two roles, chosen by blockIdx (uniform):
+//   GEOMETRY (one workgroup per 256 Gaussians and VIEW): 48 bytes in, T1, the 32-byte record + info out, the window
+//            histogram, count atomics, exact tile culling and key emit of T3; the last of a view's geometry workgroups
+//            runs that view's tail (T5).  Latency-bound (barriers, returning atomics), HBM-light.
+//   COLOUR   (one workgroup per 256 Gaussians, all views of the launch): mean + the 192 bytes of SH planes in, T2 for each
+//            view, 16 bytes per view out.  No LDS, no barrier, no atomic: a pure stream.
+// Both kinds are resident together (the block index interleaves them), so the HBM-bound stream runs UNDER the
+// latency-bound binning instead of in front of it, and the geometry blocks are weighted towards the front of the grid
+// (mix_k eighths of the leading blocks) so that the tail runs while the last colour blocks still stream.  One launch,
+// one stream: no cross-queue hop on the blocking path.
+struct ProjArgs {
+    SasCam cam[2];
+    SasFrame f[2];
+    int mix_k;                                   // of 8 consecutive leading blocks, this many are geometry blocks
+    int pose_inline;                             // 1: the group poses are pose_rows (small blocks: no upload kernel)
+    float pose_rows[12 * SAS_PROJ_INLINE_ROWS];
+};
+
+// GEOMETRY role: T1 of Gaussians [256 wg, 256 wg + 256) for ONE view, then that view's binning; reached by all 256 threads.
+template <typename RowFn>
+DEV void geom_role(const SasScene &s, const SasCam &c, const SasFrame &f, unsigned wg, const float *poses, bool poses_inline,
+                   RowFn inline_row, int *s_win, int *s_hist, int *s_base, int *s_nvis, int *s_last)
+{
+    const int64_t i = (int64_t)wg * 256 + threadIdx.x;
+    unsigned long long pl_t_ = 0ull;
+    const unsigned pl_wg_ = wg;
+    (void)pl_wg_;
+#ifdef SAS_TUNE_PTIME
+    pl_t_ = wall_clock64();
+    if (threadIdx.x == 0 && wg < (unsigned)kDbgPMax) g_dbg_plap[16 * wg + 14] = pl_t_;
+#endif
+    ViewGeom g;
+    g.vis = false; g.x0 = g.x1 = g.y0 = g.y1 = 0; g.z = 0.0f;
+    if (i < s.n) {
+        const float4 a0 = s.g0[i];
+        const float4 a1 = s.g1[i];
+        const float4 a2 = s.g2[i];
         float m[3] = {a0.x, a0.y, a0.z};
         const float op = a0.w;
-        const bool hasG = poses_inline || poses != nullptr;   // the views of one pass share their group poses
         float G[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-        const unsigned gid = __float_as_uint(a2.w) & 255u;
-        if (poses_inline) {
-            unsigned long long todo = __ballot(true);
-            while (todo) {
-                const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)todo) - 1);
-                const bool mine = gid == g;
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const float r = inline_row(g, k);   // uniform: scalar load
-                    if (mine) G[k] = r;
-                }
-                todo &= ~__ballot(mine);
-            }
-        } else if (poses) {
-            const float *Gp = poses + 12 * gid;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) G[k] = Gp[k];
-        }
+        const bool hasG = group_pose(__float_as_uint(a2.w) & 255u, poses, poses_inline, inline_row, G);
         if (hasG) {
             float mg0 = affine3(G[0], G[1], G[2], G[3], m[0], m[1], m[2]);
             float mg1 = affine3(G[4], G[5], G[6], G[7], m[0], m[1], m[2]);
             float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
             m[0] = mg0; m[1] = mg1; m[2] = mg2;
         }
-        float cx[NV], cy[NV], cz[NV];
-        bool ok[NV], any_ok = false;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const SasCam &c = vs.cam[v];   // argument segment: scalar loads
-            cx[v] = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);
-            cy[v] = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
-            cz[v] = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
-            ok[v] = !(cz[v] < kNear || cz[v] > kFar);
-            ok[v] = ok[v] && !(op < kAlphaThr);   // opacity cull moved up: it has no side effect before the det test
-            any_ok = any_ok || ok[v];
-        }
-        if (any_ok) {
-            // 3-D covariance in the world (group) frame: camera-independent
+        const float cx = affine3(c.R[0], c.R[1], c.R[2], c.t[0], m[0], m[1], m[2]);   // argument segment: scalar loads
+        const float cy = affine3(c.R[3], c.R[4], c.R[5], c.t[1], m[0], m[1], m[2]);
+        const float cz = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
+        bool ok = !(cz < kNear || cz > kFar);
+        ok = ok && !(op < kAlphaThr);   // opacity cull moved up: it has no side effect before the det test
+        if (ok) {
+            // 3-D covariance in the world (group) frame
             float cov[6];
             if (!s.cov_mode) {
                 float qw = a1.x, qx = a1.y, qy = a1.z, qz = a1.w;
@@ -774,58 +993,26 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
                     for (int k = 0; k < 6; ++k) cov[k] = c2[k];
                 }
             }
-            bool any_vis = false;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                if (ok[v]) project_view(vs.cam[v], cov, op, cx[v], cy[v], cz[v], g[v]);
-                any_vis = any_vis || g[v].vis;
-            }
-            if (any_vis) {
-                // colour: the coefficient planes are fetched once for all views
-                constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
-                constexpr int PL = (KF + 3) / 4;
-                float sh[PL * 4];
-#pragma unroll
-                for (int p = 0; p < PL; ++p) {
-                    const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
-                    sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
-                }
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    if (!g[v].vis) continue;
-                    const SasCam &c = vs.cam[v];
-                    float rgb[3];
-                    if constexpr (DEG >= 0) {
-                        sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
-                    } else {
-                        rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
-                    }
-                    const SasFrame &f = vs.f[v];
-                    if (SAS_TUNE_PABL & 8) continue;
-                    f.rec[3 * i + 0] = make_float4(g[v].mx, g[v].my, g[v].ca, g[v].cb);
-                    f.rec[3 * i + 1] = make_float4(g[v].ccn, op, g[v].thr, g[v].z);
-                    // radii (parity hook only): x in info.w, y in the record's spare word -- full 32 bits each (a camera
-                    // inside the cloud produces radii beyond 65535 pixels); saturated to INT_MAX
-                    const int irx = (int)fminf(g[v].rx, 2147483520.0f), iry = (int)fminf(g[v].ry, 2147483520.0f);
-                    f.rec[3 * i + 2] = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(iry));
-                    f.info[i] = make_uint4((unsigned)g[v].x0 | ((unsigned)g[v].x1 << 16), (unsigned)g[v].y0 | ((unsigned)g[v].y1 << 16),
-                                           __float_as_uint(g[v].z), (unsigned)irx);
-                }
-            }
+            project_view(c, cov, op, cx, cy, cz, g);
         }
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-            if (!g[v].vis) vs.f[v].info[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (g.vis) {
+            if (!(SAS_TUNE_PABL & 8)) {
+                f.rec[2 * i + 0] = make_float4(g.mx, g.my, g.ca, g.cb);
+                f.rec[2 * i + 1] = make_float4(g.ccn, op, g.thr, g.z);
+                // radii (parity hook only): full 32 bits each (a camera inside the cloud produces radii beyond 65535
+                // pixels); saturated to INT_MAX
+                const int irx = (int)fminf(g.rx, 2147483520.0f), iry = (int)fminf(g.ry, 2147483520.0f);
+                if (f.keep_info) f.info[i] = make_uint4((unsigned)g.x0 | ((unsigned)g.x1 << 16), (unsigned)g.y0 | ((unsigned)g.y1 << 16), (unsigned)irx, (unsigned)iry);
+            }
+        } else if (f.keep_info) {
+            f.info[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
-    __shared__ int s_win[4];
-    __shared__ int s_hist[kHistBins];
-    __shared__ int s_base[kHistBins];   // single-pass binning: start of the workgroup's run inside each window tile's segment
-    __shared__ int s_nvis[2];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) count_tiles(vs.f[v], vs.cam[v].tw, vs.cam[v].tile_px, g[v], (unsigned)i, s_win, s_hist, s_base, s_nvis);
-    // ---- the last workgroup to get here scans the counts of the frame(s).
+    PL_LAP(0);
+    if (!(SAS_TUNE_PABL & 128)) count_tiles(f, c.tw, c.tile_px, g, (unsigned)i, wg, s_win, s_hist, s_base, s_nvis, pl_t_);
+    // ---- the last geometry workgroup of the view to get here scans the counts of its frame.
     // Everything the tail reads from other workgroups was written by AGENT-scope atomics (the per-tile counts, the
-    // window-miss counter, wg_vis below), which are performed at the point all XCDs share; what remains is ordering:
+    // window-miss counter, wg_vis), which are performed at the point all XCDs share; what remains is ordering:
     // every wave waits until its own outstanding stores and atomics have been acknowledged (s_waitcnt vmcnt(0) -- the
     // wait an agent-scope release consists of, without its cache write-back; a workgroup-scope fence compiles to
     // nothing here), the barrier collects the waves, then thread 0 takes the ticket.  A __threadfence() in this place
@@ -834,52 +1021,180 @@ DEV void project_body(const SasScene &s, const ProjArgs &vs, const float *poses 
     // The ticket has two levels: same-address atomics serialise at ~90 per us at the memory side, and 3 907
     // workgroups taking one counter cost the projection 23 us; 64 sub-counters (one cache line each) take ~61
     // tickets each, the last taker of each takes one of 64 master tickets.
-    __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PL_LAP(7);
     if (threadIdx.x == 0) {
-        unsigned *tk = vs.f[0].tickets;
-        const unsigned sub = blockIdx.x & 63u, n_sub = (gridDim.x - sub + 63u) >> 6, subs = min(gridDim.x, 64u);
+        unsigned *tk = f.tickets;
+        const unsigned n_wg = (unsigned)f.n_wg;
+        const unsigned sub = wg & 63u, n_sub = (n_wg - sub + 63u) >> 6, subs = min(n_wg, 64u);
         int last = 0;
         if (atomicAdd(&tk[32u * sub], 1u) == n_sub - 1u) {
             tk[32u * sub] = 0u;                                   // nobody else touches it any more in this frame
             last = atomicAdd(&tk[32u * 64u], 1u) == subs - 1u;
             if (last) tk[32u * 64u] = 0u;
         }
-        s_last = last;
+        *s_last = last;
     }
     __syncthreads();
-    if (!s_last) return;
+    PL_LAP(8);
+#ifdef SAS_TUNE_PTIME
+    if (threadIdx.x == 0 && wg < (unsigned)kDbgPMax) g_dbg_plap[16 * wg + 15] = wall_clock64();
+#endif
+    if (!*s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the tail's loads below are not served from a stale cache line
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        scan_tail(&vs.f[v], s_hist);
-        __syncthreads();
-    }
+#ifndef SAS_TUNE_NOTAIL
+    if (f.seg > 0) scan_tail_single(&f, s_hist, pl_wg_, pl_t_);   // (uniform)
+    else scan_tail<false>(&f, s_hist);
+#endif
+    PL_LAP(9);
+#ifdef SAS_TUNE_PTIME
+    if (threadIdx.x == 0 && wg < (unsigned)kDbgPMax) g_dbg_plap[16 * wg + 15] = wall_clock64();
+#endif
 }
 
-// (k_project<3,1> takes 81 registers since the tail orders the tiles, five waves per SIMD instead of seven: forcing six or
-// seven -- amdgpu_waves_per_eu, the excess spilling inside the tail -- moved the projection by 1 % and nothing else)
-#ifdef SAS_TUNE_POCC   // A/B builds: waves per SIMD forced for the projection (the pair projection takes 103 registers: four waves)
+// COLOUR role: T2 of Gaussians [256 wg, 256 wg + 256) for every view of the launch.  A pure stream: no LDS, no barrier.
+// The colour of a Gaussian that the geometry role culls (off screen, degenerate) is computed all the same -- nobody
+// reads it; only what is decided by the mean and the opacity alone is decided here too, with the geometry role's own
+// expressions (near / far plane, transparent), so that scenes mostly behind the camera do not stream their planes.
+template <int DEG, int NV, typename RowFn>
+DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const float *poses, bool poses_inline, RowFn inline_row)
+{
+    const int64_t i = (int64_t)wg * 256 + threadIdx.x;
+#ifdef SAS_TUNE_PTIME
+    if (threadIdx.x == 0 && wg < (unsigned)kDbgPMax) g_dbg_pcol[2 * wg] = wall_clock64();
+#endif
+    if (i >= s.n) return;
+    const float4 a0 = s.g0[i];
+    float m[3] = {a0.x, a0.y, a0.z};
+    const float op = a0.w;
+    if (s.n_groups > 0) {   // (uniform)
+        float G[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+        if (group_pose((unsigned)s.gid8[i], poses, poses_inline, inline_row, G)) {
+            float mg0 = affine3(G[0], G[1], G[2], G[3], m[0], m[1], m[2]);
+            float mg1 = affine3(G[4], G[5], G[6], G[7], m[0], m[1], m[2]);
+            float mg2 = affine3(G[8], G[9], G[10], G[11], m[0], m[1], m[2]);
+            m[0] = mg0; m[1] = mg1; m[2] = mg2;
+        }
+    }
+    bool ok[NV], any_ok = false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const SasCam &c = vs.cam[v];
+        const float cz = affine3(c.R[6], c.R[7], c.R[8], c.t[2], m[0], m[1], m[2]);
+        ok[v] = !(cz < kNear || cz > kFar) && !(op < kAlphaThr);
+        any_ok = any_ok || ok[v];
+    }
+    if (!any_ok) return;
+    constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
+    constexpr int PL = (KF + 3) / 4;
+    float sh[PL * 4];
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+        const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
+        sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (!ok[v]) continue;
+        const SasCam &c = vs.cam[v];
+        float rgb[3];
+        if constexpr (DEG >= 0) {
+            sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
+        } else {
+            rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
+        }
+        if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+    }
+#ifdef SAS_TUNE_PTIME
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (instrumented build: the stamp is taken when the stores have been acknowledged)
+    if (threadIdx.x == 0 && wg < (unsigned)kDbgPMax) g_dbg_pcol[2 * wg + 1] = wall_clock64();
+#endif
+}
+
+// Block -> role.  n_geo geometry blocks and n_col colour blocks share the grid; of every 8 leading blocks mix_k are
+// geometry blocks until those are used up: geo_before(b) = min(n_geo, ceil(b * mix_k / 8)) geometry blocks lie in front
+// of block b.  (mix_k / 8 >= n_geo / (n_geo + n_col): the launchers see to it -- every geometry block gets a place.)
+struct Role {
+    bool geom;
+    unsigned idx;   // index among the blocks of the role
+};
+// Geometry blocks do not take their chunks of 256 Gaussians in storage order: a chunk's binning work follows its
+// Gaussians' footprints, the scene is stored along a space-filling curve, so the chunks near the camera -- several times
+// the tiles per Gaussian -- are neighbours in storage order, and dispatched in that order they would start together and
+// late and end the launch on a long run of stragglers (tools/proj_time.py: 90 % of the geometry done at 56 us, the last
+// workgroup at 70).  Dispatch index -> chunk is a transpose over kSpreadRows rows: consecutive blocks are n_wg / 16
+// chunks apart, any run of heavy chunks is spread over the whole launch.  (Blocks whose chunk lies past the end leave.)
+constexpr unsigned kSpreadRows = 16;
+DEV unsigned spread_cols(unsigned n_wg) { return (n_wg + kSpreadRows - 1u) / kSpreadRows; }
+DEV unsigned spread_chunk(unsigned gi, unsigned n_wg) { return (gi % kSpreadRows) * spread_cols(n_wg) + gi / kSpreadRows; }
+DEV Role block_role(unsigned b, unsigned n_geo, unsigned mix_k)
+{
+    const unsigned g0 = min(n_geo, (b * mix_k + 7u) >> 3), g1 = min(n_geo, ((b + 1u) * mix_k + 7u) >> 3);
+    Role r;
+    r.geom = g1 > g0;
+    r.idx = r.geom ? g0 : b - g0;
+    return r;
+}
+
+#ifdef SAS_TUNE_POCC   // A/B builds: waves per SIMD forced for the projection
 #define SAS_PROJECT_ATTRS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAS_TUNE_POCC, SAS_TUNE_POCC)))
 #else
 #define SAS_PROJECT_ATTRS __launch_bounds__(256)
 #endif
+// grid.x = (NV + 1) * n_wg: NV * n_wg geometry blocks (view = index % NV: the views' blocks of one chunk of Gaussians are
+// neighbours in dispatch order and share its 48 bytes through the cache) and n_wg colour blocks
 template <int DEG, int NV>
 __global__ SAS_PROJECT_ATTRS void k_project(SasScene s, ProjArgs vs)
 {
-    project_body<DEG, NV>(s, vs, vs.f[0].group_Rt, vs.pose_inline != 0, [&](unsigned g, int k) { return vs.pose_rows[12u * g + (unsigned)k]; });
+    __shared__ int s_win[4];
+    __shared__ __attribute__((aligned(16))) int s_bins2[2 * kHistBins];   // one block: the tail uses all 16 KiB of it
+    int *const s_hist = s_bins2;
+    int *const s_base = s_bins2 + kHistBins;   // single-pass binning: start of the workgroup's run inside each window tile's segment
+    __shared__ int s_nvis[2];
+    __shared__ int s_last;
+    const unsigned n_wg = (unsigned)vs.f[0].n_wg;
+    const Role r = block_role(blockIdx.x, (unsigned)NV * kSpreadRows * spread_cols(n_wg), (unsigned)vs.mix_k);
+    auto row = [&](unsigned g, int k) { return vs.pose_rows[12u * g + (unsigned)k]; };
+    if (!r.geom) {
+        if (!(SAS_TUNE_PABL & 32) && r.idx < n_wg) color_role<DEG, NV>(s, vs, r.idx, vs.f[0].group_Rt, vs.pose_inline != 0, row);
+        return;
+    }
+    if (SAS_TUNE_PABL & 64) return;
+    const unsigned wg = spread_chunk(NV == 1 ? r.idx : r.idx >> 1, n_wg);
+    if (wg >= n_wg) return;
+    // (two inlined copies for a pair, chosen by a uniform branch: the view's camera and frame are then read from the
+    // argument segment at constant offsets; indexing them by a run-time view would copy them to registers or scratch)
+    if (NV == 1 || (r.idx & 1u) == 0u)
+        geom_role(s, vs.cam[0], vs.f[0], wg, vs.f[0].group_Rt, vs.pose_inline != 0, row, s_win, s_hist, s_base, s_nvis, &s_last);
+    else
+        geom_role(s, vs.cam[1], vs.f[1], wg, vs.f[0].group_Rt, vs.pose_inline != 0, row, s_win, s_hist, s_base, s_nvis, &s_last);
 }
 
-// all views of a group in one launch: blockIdx.y = view, one pass over the (small) scene per view
+// all views of a group in one launch: blockIdx.y = view, one pass over the (small) scene per view, both roles per view
 template <int DEG>
 __global__ __launch_bounds__(256) void k_project_multi(SasScene s, SasMulti mf)
 {
+    __shared__ int s_win[4];
+    __shared__ __attribute__((aligned(16))) int s_bins2[2 * kHistBins];
+    int *const s_hist = s_bins2;
+    int *const s_base = s_bins2 + kHistBins;
+    __shared__ int s_nvis[2];
+    __shared__ int s_last;
     ProjArgs vs;
     vs.cam[0] = vs.cam[1] = mf.P[blockIdx.y].cam;
     vs.f[0] = vs.f[1] = mf.f[blockIdx.y];
     const unsigned off = (unsigned)mf.pose_off[blockIdx.y];
-    project_body<DEG, 1>(s, vs, mf.f[blockIdx.y].group_Rt, mf.pose_inline != 0, [&](unsigned g, int k) { return mf.pose_rows[off + 12u * g + (unsigned)k]; });
+    auto row = [&](unsigned g, int k) { return mf.pose_rows[off + 12u * g + (unsigned)k]; };
+    const unsigned n_wg = (unsigned)vs.f[0].n_wg;
+    const Role r = block_role(blockIdx.x, kSpreadRows * spread_cols(n_wg), (unsigned)mf.mix_k);
+    if (!r.geom) {
+        if (r.idx < n_wg) color_role<DEG, 1>(s, vs, r.idx, mf.f[blockIdx.y].group_Rt, mf.pose_inline != 0, row);
+        return;
+    }
+    const unsigned wg = spread_chunk(r.idx, n_wg);
+    if (wg >= n_wg) return;
+    geom_role(s, vs.cam[0], vs.f[0], wg, mf.f[blockIdx.y].group_Rt, mf.pose_inline != 0, row, s_win, s_hist, s_base, s_nvis, &s_last);
 }
 
 // ---- small kernels around a frame ---------------------------------------------------------------------
@@ -978,7 +1293,8 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
     if (i < s.n) inf = f.info[i];
     const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
     const bool vis = x1 > x0 && y1 > y0;
-    const unsigned long long key = ((unsigned long long)inf.z << 32) | (unsigned long long)(unsigned)i;
+    const unsigned zbits = vis ? __float_as_uint(f.rec[2 * i + 1].w) : 0u;   // (info holds the rectangle and the radii; the depth is the record's)
+    const unsigned long long key = ((unsigned long long)zbits << 32) | (unsigned long long)(unsigned)i;
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
     const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
@@ -1039,18 +1355,31 @@ SAS_BOUNDS_ACCESSOR(sas_debug_bounds_kernels)
 void sas_launch_relayout(hipStream_t st, int64_t n, int64_t n_pad, const int *perm, const float *means, const float *quats,
                          const float *scales, const float *cov6, const float *opac, const float *colors,
                          int coeff_floats, int planes, const uint8_t *gid, float4 *g0, float4 *g1, float4 *g2,
-                         float4 *col)
+                         float4 *col, uint8_t *gid8)
 {
     if (n <= 0) return;
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, n, n_pad, perm, means, quats, scales, cov6, opac, colors,
-                       coeff_floats, planes, gid, g0, g1, g2, col);
+                       coeff_floats, planes, gid, g0, g1, g2, col, gid8);
+}
+
+static unsigned sas_spread_blocks(unsigned n_wg) { return 16u * ((n_wg + 15u) / 16u); }   // kSpreadRows * spread_cols
+// geometry blocks per 8 leading blocks (block_role): enough for every geometry block to get a place, weighted so that the
+// geometry -- whose last workgroup runs the serial tail -- is dispatched ahead of the last colour blocks.  SAS_PROJ_MIX=k overrides.
+static int project_mix(int nv, unsigned n_wg)
+{
+    static const int env = [] { const char *e = getenv("SAS_PROJ_MIX"); return e ? atoi(e) : 0; }();
+    const unsigned n_geo = (unsigned)nv * sas_spread_blocks(n_wg), total = n_geo + n_wg;
+    const int kmin = (int)((8u * n_geo + total - 1u) / total);
+    const int k = env > 0 ? env : (nv == 1 ? 6 : 7);
+    return k < kmin ? kmin : (k > 8 ? 8 : k);
 }
 
 template <int NV>
 static void launch_project(hipStream_t st, const SasScene &s, const ProjArgs &vs)
 {
-    const unsigned grid = (unsigned)vs.f[0].n_wg;   // >= 1: an empty scene still takes the tail
+    const unsigned n_wg = (unsigned)vs.f[0].n_wg;   // >= 1: an empty scene still takes the tail
+    const unsigned grid = (unsigned)NV * sas_spread_blocks(n_wg) + n_wg;   // geometry blocks (per view, padded to the spread's rows) + colour blocks
     switch (s.sh_degree) {
         case 0: hipLaunchKernelGGL((k_project<0, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
         case 1: hipLaunchKernelGGL((k_project<1, NV>), dim3(grid), dim3(256), 0, st, s, vs); break;
@@ -1071,6 +1400,7 @@ void sas_launch_project(hipStream_t st, const SasScene &s, const SasParams &P, c
     ProjArgs vs;
     vs.cam[0] = vs.cam[1] = P.cam;
     vs.f[0] = vs.f[1] = f;
+    vs.mix_k = project_mix(1, (unsigned)f.n_wg);
     inline_poses(vs, s);
     launch_project<1>(st, s, vs);
 }
@@ -1081,6 +1411,7 @@ void sas_launch_project2(hipStream_t st, const SasScene &s, const SasParams &P0,
     ProjArgs vs;
     vs.cam[0] = P0.cam; vs.cam[1] = P1.cam;
     vs.f[0] = f0; vs.f[1] = f1;
+    vs.mix_k = project_mix(2, (unsigned)f0.n_wg);
     inline_poses(vs, s);
     launch_project<2>(st, s, vs);
 }
@@ -1095,7 +1426,8 @@ void sas_launch_project_multi(hipStream_t st, const SasScene &s, const SasMulti 
         mf.pose_off[k] = 12 * s.n_groups * k;
         memcpy(mf.pose_rows + mf.pose_off[k], mf.f[k].group_host, sizeof(float) * 12 * (size_t)s.n_groups);
     }
-    const dim3 grid((unsigned)mf.f[0].n_wg, (unsigned)mf.nv);
+    mf.mix_k = project_mix(1, (unsigned)mf.f[0].n_wg);
+    const dim3 grid(sas_spread_blocks((unsigned)mf.f[0].n_wg) + (unsigned)mf.f[0].n_wg, (unsigned)mf.nv);   // geometry + colour blocks per view
     switch (s.sh_degree) {
         case 0: hipLaunchKernelGGL((k_project_multi<0>), grid, dim3(256), 0, st, s, mf); break;
         case 1: hipLaunchKernelGGL((k_project_multi<1>), grid, dim3(256), 0, st, s, mf); break;

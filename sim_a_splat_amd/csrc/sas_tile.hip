@@ -610,7 +610,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     bool have = false;
 #ifdef SAS_TUNE_STATS
-    unsigned dbg_rx = 0u;
+    unsigned dbg_rx = 0u, dbg_ry = 0u;
 #endif
     const float sE5 = vgpr_const(0x3aafa464u);   // leading exp coefficient
     // only issues the loads: nothing here may depend on their results
@@ -620,11 +620,12 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         if (have) {
             long long id = slot_at(idx);
             if (!SAS_IN(id, n_gauss, 201) || id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
-            ra = f.rec[3 * id + 0];
-            rb = f.rec[3 * id + 1];
-            rc = f.rec[3 * id + 2];
+            ra = f.rec[2 * id + 0];
+            rb = f.rec[2 * id + 1];
+            rc = f.col[id];
 #ifdef SAS_TUNE_STATS
-            dbg_rx = f.info[id].w;
+            dbg_rx = f.info[id].z;
+            dbg_ry = f.info[id].w;
 #endif
         }
     };
@@ -665,7 +666,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         {   // how many queued (entry, block) pairs would the splat's own bounding box (its radii) remove?
             unsigned keep = 0u;
             if (have) {
-                const float rx = (float)(int)dbg_rx, ry = (float)__float_as_int(rc.w);
+                const float rx = (float)(int)dbg_rx, ry = (float)(int)dbg_ry;
                 for (int b = 0; b < 16; ++b) {
                     const float x0 = (float)(tx * SAS_TILE + 4 * (b & 3)) + 0.5f, y0 = (float)(ty * SAS_TILE + 4 * (b >> 2)) + 0.5f;
                     const bool out = x0 > ra.x + rx || x0 + 3.0f < ra.x - rx || y0 > ra.y + ry || y0 + 3.0f < ra.y - ry;
@@ -884,9 +885,9 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
             id &= 1023;   // timing experiment: the records come from 48 KiB that stay in the caches (wrong images)
 #endif
             if (!SAS_IN(id, n_gauss, 231) || id >= n_gauss) id = n_gauss - 1;
-            ra = f.rec[3 * id + 0];
-            rb = f.rec[3 * id + 1];
-            rc = f.rec[3 * id + 2];
+            ra = f.rec[2 * id + 0];
+            rb = f.rec[2 * id + 1];
+            rc = f.col[id];
         }
     };
     if (count > 0) fetch(0);
@@ -1221,8 +1222,17 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
 #endif
     // QUAD: the frame is binned in 8-pixel tiles (c.tile_px == 8): this workgroup's tile is the 8x8 quadrant qd of the
     // contract's 16-pixel tile (tx, ty), whose origin the sigma polynomials refer to (pixel_of_quad); the list is its own
-    const int tile = f.tile_order[wg];
-    if (!SAS_IN(tile, f.n_tiles, 213)) return;   // uniform
+    // single-pass frames: the projection's tail orders GROUPS of four consecutive tiles (by their longest list); two-pass frames: tiles
+    // (the grid is the tile count rounded up to whole groups: the last group may be ragged; all of this is uniform)
+    int tile;
+    if (f.seg > 0) {
+        tile = 4 * f.tile_order[wg >> 2] + (int)(wg & 3u);
+        if (tile >= f.n_tiles) return;
+    } else {
+        if (wg >= (unsigned)f.n_tiles) return;
+        tile = f.tile_order[wg];
+    }
+    if (!SAS_IN(tile, f.n_tiles, 213)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int tx = tile % c.tw, ty = tile / c.tw;
     int qd = 0;
@@ -1478,13 +1488,13 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                     }
                 }
             } else {
-                // the chunk is one contiguous run of the bucket-ordered slots; depth words come from the projection's info
+                // the chunk is one contiguous run of the bucket-ordered slots; depth words come from the projection's records
                 // buckets are consumed whole and in order, so the chunk starts where the previous ones ended
                 const int st = p_consumed, cnt_chunk = (int)s_m;
                 for (int i = tid; i < cnt_chunk; i += kLazyThreads) {
                     if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, CH, 217)) continue;
                     const unsigned slot = (unsigned)ids[st + i];
-                    const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? f.info[slot].z : dmin;
+                    const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? __float_as_uint(f.rec[2 * (long long)slot + 1].w) : dmin;
                     ck[i] = ((unsigned long long)(dbits - base) << 32) | slot;
                 }
             }
@@ -1703,7 +1713,7 @@ bool sas_tiles_lazy_quad_ok(bool fast_exp) { return !fast_exp; }
 void sas_launch_tiles_lazy(hipStream_t st, const SasScene &s, int tiles, const SasParams &P, const SasFrame &f,
                            bool fast_exp, bool want_max, bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const unsigned grid = (unsigned)tiles;
+    const unsigned grid = ((unsigned)tiles + 3u) & ~3u;   // whole groups of four tiles (tile_lazy_body)
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
         if (want_max) launch_lazy<true, true, false>(st, grid, P, f, n, s.perm, ev_start, ev_stop);
@@ -1729,7 +1739,7 @@ static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, lon
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,
                                  bool quad, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid((unsigned)tiles * (unsigned)mf.nv);   // views interleaved (k_tile_lazy_multi)
+    const dim3 grid((((unsigned)tiles + 3u) & ~3u) * (unsigned)mf.nv);   // views interleaved (k_tile_lazy_multi); whole groups of four tiles per view
     const long long n = s.n > 0 ? s.n : 1;
     if (fast_exp) {
         if (want_max) launch_lazy_multi<true, true, false>(st, grid, mf, n, s.perm, ev_start, ev_stop);

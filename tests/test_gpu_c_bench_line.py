@@ -39,6 +39,13 @@ def test_bench_line_schema_at_the_drivers_command_shape():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 100                                # reported beside, not the target
-    assert d["value_protocol_version"] == 2 and d["effective_warmup_steps"] >= 2 and len(d["passes"]) >= 1
+    assert d["value_protocol_version"] == 3 and d["effective_warmup_steps"] >= 2 and len(d["passes"]) >= 1
     assert abs(d["cold_start"]["value"] - d["passes"][0]["value"]) < 1e-6 * d["value"]
+    # value = the median of the passes behind the clock ramp (not whichever pass the cap fell on), with its own disclosures
+    assert isinstance(d["converged"], bool) and d["pass_spread"] >= 0.0 and 1 <= d["passes_behind_ramp"] <= len(d["passes"])
+    behind = sorted(p_["value"] for p_ in d["passes"][len(d["passes"]) - d["passes_behind_ramp"]:])
+    assert behind[0] * (1 - 1e-9) <= d["value"] <= behind[-1] * (1 + 1e-9)
     assert d["door_a_sync"]["value"] > 1000 and d["single_view_async"]["value"] > 1000
+    # every output of Door A, pipelined (rgb + accumulation + depth with the fill): not slower than the blocking form
+    assert d["door_a_async"]["value"] >= 0.95 * d["door_a_sync"]["value"] and d["door_a_async"]["frames"] >= 50
+    assert "door_a_async" in d["config"]["workload"]                    # the line says what `value` does not write
