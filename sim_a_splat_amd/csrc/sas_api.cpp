@@ -52,6 +52,11 @@ struct Scratch {
     bool seg_too_big = false;     // ... segments for this slot's frames would exceed the memory budget: two-pass binning instead
     int seg_tiles = -1;           // the tile count and scene size `seg` / `seg_too_big` were established for: another frame size or scene
     int64_t seg_n = -1;           // sizes the segments afresh (a slot that once met a pathological frame does not stay two-pass for good)
+    // what the slot has learned about other (tile count, scene size) pairs it has rendered: a slot that alternates between two
+    // camera sizes neither carries one size's segment length over to the other nor guesses (and overflows) anew at every change
+    struct SegMemo { int tiles; int64_t n; long long seg; };
+    SegMemo seg_memo[4] = {{-1, -1, 0}, {-1, -1, 0}, {-1, -1, 0}, {-1, -1, 0}};
+    int seg_memo_next = 0;
     bool counters_zero = false;   // the counter block is known to be all zero (SasFrame invariant)
 };
 
@@ -125,9 +130,10 @@ struct sas_ctx {
     // quad layout (the frame binned in 8-pixel tiles, one workgroup per 8x8 quadrant): -1 = for views of at most
     // quad_max_tiles 16-pixel tiles, 0 = never, 1 = always (SAS_QUAD, SAS_QUAD_TILES)
     // single-pass binning (fixed-stride tile segments, the projection emits the keys): -1 = whenever the segments fit
-    // direct_budget bytes per slot, 0 = never (SAS_DIRECT=0: the two-pass path of rounds 1-3)
+    // direct_budget bytes per CONTEXT (all its frame slots together: a slot's keys + ids may take direct_budget / n_slots), 0 =
+    // never (SAS_DIRECT=0: the two-pass path of rounds 1-3).  24 GB: config 5's 6.4 GB per slot; of 288 GB of HBM
     int direct_mode = -1;
-    long long direct_budget = 6ll << 30;
+    long long direct_budget = 24ll << 30;
     // exact tile culling on single-pass frames (sas_kernels.hip: tile_reached); SAS_CULL=0 bins whole rectangles as T3 does
     int cull_mode = 1;
     int seg_guess_factor = 16;    // first guess of a tile segment = this x the mean list of a frame with five intersections per Gaussian (SAS_SEG_FACTOR)
@@ -384,7 +390,7 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
         if (want < (1ll << 20)) want = 1ll << 20;
         q.cap = want;
     }
-    if ((rc = ensure(c, q.rec, sizeof(float4) * 2 * (size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = ensure(c, q.rec, sizeof(float4) * SAS_RS * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.col, sizeof(float4) * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.info, sizeof(uint4) * (size_t)(n > 0 ? n : 1)))) return rc;
     if ((rc = ensure(c, q.tilebuf, sizeof(int) * (3 * sas_tile_stride(tiles) + 16)))) return rc;
@@ -403,9 +409,20 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
     // Single-pass binning: every tile owns a segment of q.seg keys.  First guess: 16 x the mean list of a frame with five
     // intersections per Gaussian, a power of two (config 3: 16 384 keys = 1.6 GB of keys + ids per slot; its longest list
     // is ~6 k); a frame whose longest list outgrows it is rendered again with larger segments (complete_oldest).
+    const long long slot_budget = c->direct_budget / std::max(1, c->n_slots);   // the budget is the context's: its slots share it
     if (q.seg_tiles != tiles || q.seg_n != n) {
+        // another frame size or scene: remember what this one had learned, take up what the slot knows about the new one
+        // (else 0: guessed below -- a segment length learned on a 300-tile frame says nothing about a 1 200-tile one)
+        if (q.seg_tiles >= 0 && q.seg > 0) {
+            int k = 0;
+            while (k < 4 && !(q.seg_memo[k].tiles == q.seg_tiles && q.seg_memo[k].n == q.seg_n)) ++k;
+            if (k == 4) { k = q.seg_memo_next; q.seg_memo_next = (q.seg_memo_next + 1) % 4; }
+            q.seg_memo[k] = {q.seg_tiles, q.seg_n, q.seg};
+        }
+        q.seg = 0;
+        for (const auto &m : q.seg_memo)
+            if (m.tiles == tiles && m.n == n) q.seg = m.seg;
         q.seg_too_big = false;
-        if (q.seg && (long long)tiles * q.seg * 12 > c->direct_budget) q.seg = 0;   // learned on smaller frames: guessed anew below
         q.seg_tiles = tiles;
         q.seg_n = n;
     }
@@ -417,17 +434,25 @@ int prepare_frame(sas_ctx *c, Slot &sl, hipStream_t init_st)
             while (s2 < guess) s2 <<= 1;
             q.seg = s2;
         }
-        if ((long long)tiles * q.seg * 12 > c->direct_budget || q.seg > (1ll << 30)) {
+        if ((long long)tiles * q.seg * 12 > slot_budget || q.seg > (1ll << 30)) {
             sl.direct = false;          // pathological concentration (or a huge frame): the two-pass path has no such limit
             q.seg_too_big = true;
         }
     }
     size_t n_keys = sl.direct ? (size_t)tiles * (size_t)q.seg : (size_t)q.cap;
+    {   // buffers sized for a much larger frame (or for segments the slot has since given up) go back to the allocator:
+        // several contexts share a card (vectorised ranks, torch), and ensure() by itself only ever grows
+        const size_t want_keys = sizeof(unsigned long long) * std::max(n_keys, (size_t)q.cap);
+        if (q.keys.bytes > 4 * want_keys && q.keys.bytes > (256u << 20)) { release(q.keys); release(q.ids); }
+    }
     if (sl.direct && (ensure(c, q.keys, sizeof(unsigned long long) * std::max(n_keys, (size_t)q.cap)) ||
                       ensure(c, q.ids, sizeof(int) * std::max(n_keys, (size_t)q.cap)))) {
         // the segments do not fit this GPU's free memory: not an error, the two-pass path needs 12 bytes per intersection only
+        // (whatever of the segment-sized pair was allocated is released: the compact lists take a fraction of it)
         (void)hipGetLastError();
         c->err.clear();
+        release(q.keys);
+        release(q.ids);
         sl.direct = false;
         q.seg_too_big = true;
         n_keys = (size_t)q.cap;
@@ -680,9 +705,9 @@ int complete_oldest(sas_ctx *c)
             if (mem[k]->direct) { if (want_seg > mem[k]->scr.seg) mem[k]->scr.seg = want_seg; }
             else if (want > mem[k]->scr.cap) mem[k]->scr.cap = want;
         }
-        for (Slot &o : c->slots) {   // the other slots will need it too
+        for (Slot &o : c->slots) {   // the other slots will need it too (those set up for the same frame size and scene)
             if (o.busy) continue;
-            if (want_seg && o.scr.seg && o.scr.seg < want_seg) o.scr.seg = want_seg;
+            if (want_seg && o.scr.seg && o.scr.seg < want_seg && o.scr.seg_tiles == sl.scr.seg_tiles && o.scr.seg_n == sl.scr.seg_n) o.scr.seg = want_seg;
             if (!want_seg && o.scr.cap && o.scr.cap < want) o.scr.cap = want;
         }
         c->regrows++;

@@ -4,6 +4,11 @@
 #include <stdint.h>
 
 #define SAS_TILE 16
+// record / colour strides in float4: a 32-byte record and a colour array of its own.  (Measured against the colour inside a
+// 48-byte record as rounds 1-4 had it, the two roles of the projection each writing part of every line: projection +5 us, tile
+// kernel +1.5 us, pair bench -5 %: profiles/r05_ab_record_layout.txt.)
+#define SAS_RS 2
+#define SAS_CS 1
 #define SAS_MAX_GROUP 4   // views per launch group (SasMulti)
 
 // Per-frame camera constants, computed on the host with the same f32 operations the oracle uses.

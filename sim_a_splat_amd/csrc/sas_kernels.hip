@@ -63,53 +63,65 @@ __global__ __launch_bounds__(256) void k_relayout(int64_t n, int64_t n_pad, cons
 template <int DEG>
 DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 {
+    // Degree by degree, the three channels inside: a channel's sum is the same fused chain in coefficient order as in
+    // oracle/sas_oracle.c (sh_to_color), but only one degree's basis values are alive at a time (registers: the pair
+    // projection's colour role holds the 48 coefficients across two evaluations).
     float inorm = 1.0f / sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
     float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = 0.2820947917738781f * sh[0 * 3 + c];
+    if constexpr (DEG >= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = fma_(-x, sh[3 * 3 + c], fma_(z, sh[2 * 3 + c], (-y) * sh[1 * 3 + c]));
+            r[c] = fma_(0.48860251190292f, t, r[c]);
+        }
+    }
     float z2 = z * z;
-    float fTmp0B = -1.092548430592079f * z;
     float fC1 = fma_(x, x, -(y * y));
     float fS1 = 2.0f * x * y;
-    float pSH6 = fma_(0.9461746957575601f, z2, -0.3153915652525201f);
-    float pSH7 = fTmp0B * x;
-    float pSH5 = fTmp0B * y;
-    float pSH8 = 0.5462742152960395f * fC1;
-    float pSH4 = 0.5462742152960395f * fS1;
-    float fTmp0C = fma_(-2.285228997322329f, z2, 0.4570457994644658f);
-    float fTmp1B = 1.445305721320277f * z;
-    float fC2 = fma_(x, fC1, -(y * fS1));
-    float fS2 = fma_(x, fS1, y * fC1);
-    float pSH12 = z * fma_(1.865881662950577f, z2, -1.119528997770346f);
-    float pSH13 = fTmp0C * x;
-    float pSH11 = fTmp0C * y;
-    float pSH14 = fTmp1B * fC1;
-    float pSH10 = fTmp1B * fS1;
-    float pSH15 = -0.5900435899266435f * fC2;
-    float pSH9 = -0.5900435899266435f * fS2;
+    if constexpr (DEG >= 2) {
+        float fTmp0B = -1.092548430592079f * z;
+        float pSH6 = fma_(0.9461746957575601f, z2, -0.3153915652525201f);
+        float pSH7 = fTmp0B * x;
+        float pSH5 = fTmp0B * y;
+        float pSH8 = 0.5462742152960395f * fC1;
+        float pSH4 = 0.5462742152960395f * fS1;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float r = 0.2820947917738781f * sh[0 * 3 + c];
-        if constexpr (DEG >= 1) {
-            float t = fma_(-x, sh[3 * 3 + c], fma_(z, sh[2 * 3 + c], (-y) * sh[1 * 3 + c]));
-            r = fma_(0.48860251190292f, t, r);
+        for (int c = 0; c < 3; ++c) {
+            r[c] = fma_(pSH4, sh[4 * 3 + c], r[c]);
+            r[c] = fma_(pSH5, sh[5 * 3 + c], r[c]);
+            r[c] = fma_(pSH6, sh[6 * 3 + c], r[c]);
+            r[c] = fma_(pSH7, sh[7 * 3 + c], r[c]);
+            r[c] = fma_(pSH8, sh[8 * 3 + c], r[c]);
         }
-        if constexpr (DEG >= 2) {
-            r = fma_(pSH4, sh[4 * 3 + c], r);
-            r = fma_(pSH5, sh[5 * 3 + c], r);
-            r = fma_(pSH6, sh[6 * 3 + c], r);
-            r = fma_(pSH7, sh[7 * 3 + c], r);
-            r = fma_(pSH8, sh[8 * 3 + c], r);
-        }
-        if constexpr (DEG >= 3) {
-            r = fma_(pSH9, sh[9 * 3 + c], r);
-            r = fma_(pSH10, sh[10 * 3 + c], r);
-            r = fma_(pSH11, sh[11 * 3 + c], r);
-            r = fma_(pSH12, sh[12 * 3 + c], r);
-            r = fma_(pSH13, sh[13 * 3 + c], r);
-            r = fma_(pSH14, sh[14 * 3 + c], r);
-            r = fma_(pSH15, sh[15 * 3 + c], r);
-        }
-        rgb[c] = fmaxf(r + 0.5f, 0.0f);
     }
+    if constexpr (DEG >= 3) {
+        float fTmp0C = fma_(-2.285228997322329f, z2, 0.4570457994644658f);
+        float fTmp1B = 1.445305721320277f * z;
+        float fC2 = fma_(x, fC1, -(y * fS1));
+        float fS2 = fma_(x, fS1, y * fC1);
+        float pSH12 = z * fma_(1.865881662950577f, z2, -1.119528997770346f);
+        float pSH13 = fTmp0C * x;
+        float pSH11 = fTmp0C * y;
+        float pSH14 = fTmp1B * fC1;
+        float pSH10 = fTmp1B * fS1;
+        float pSH15 = -0.5900435899266435f * fC2;
+        float pSH9 = -0.5900435899266435f * fS2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r[c] = fma_(pSH9, sh[9 * 3 + c], r[c]);
+            r[c] = fma_(pSH10, sh[10 * 3 + c], r[c]);
+            r[c] = fma_(pSH11, sh[11 * 3 + c], r[c]);
+            r[c] = fma_(pSH12, sh[12 * 3 + c], r[c]);
+            r[c] = fma_(pSH13, sh[13 * 3 + c], r[c]);
+            r[c] = fma_(pSH14, sh[14 * 3 + c], r[c]);
+            r[c] = fma_(pSH15, sh[15 * 3 + c], r[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(r[c] + 0.5f, 0.0f);
 }
 
 // Visit every tile of a rectangle.  Small rectangles are walked by their own lane; a lane with a
@@ -209,6 +221,38 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
     Window w;
     w.X0 = s_win[0]; w.Y0 = s_win[1];
     const int X1 = s_win[2], Y1 = s_win[3];
+    w.ww = X1 - w.X0;
+    w.area = (X1 > w.X0 && Y1 > w.Y0) ? w.ww * (Y1 - w.Y0) : 0;
+    w.fits = w.area > 0 && w.area <= kHistBins;
+    return w;
+}
+
+// The projection's form of wg_window: ONE barrier instead of two and no LDS atomics -- every wave leaves its four extrema in
+// its own words of s_win16, all threads reduce the sixteen; the window's bins (all kHistBins of them: eight words per thread)
+// are zeroed in front of the same barrier, so the count pass starts right behind it.  (A geometry workgroup is resident for
+// ~17 us, of which its barriers and their stragglers are a good part: tools/proj_time.py.)
+DEV Window wg_window_zeroed(bool part, int x0, int x1, int y0, int y1, int *s_win16, int *s_hist)
+{
+    int mnx = part ? x0 : 0x7fffffff, mny = part ? y0 : 0x7fffffff;
+    int mxx = part ? x1 : 0, mxy = part ? y1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, d));
+        mny = min(mny, __shfl_xor(mny, d));
+        mxx = max(mxx, __shfl_xor(mxx, d));
+        mxy = max(mxy, __shfl_xor(mxy, d));
+    }
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<int4 *>(s_win16 + 4 * (threadIdx.x >> 6)) = make_int4(mnx, mny, mxx, mxy);
+    static_assert(kHistBins == 2048, "eight bins per thread");
+    reinterpret_cast<int4 *>(s_hist)[threadIdx.x] = make_int4(0, 0, 0, 0);
+    reinterpret_cast<int4 *>(s_hist)[256 + threadIdx.x] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const int4 a = reinterpret_cast<const int4 *>(s_win16)[0], b = reinterpret_cast<const int4 *>(s_win16)[1],
+               c = reinterpret_cast<const int4 *>(s_win16)[2], d = reinterpret_cast<const int4 *>(s_win16)[3];
+    Window w;
+    w.X0 = min(min(a.x, b.x), min(c.x, d.x));
+    w.Y0 = min(min(a.y, b.y), min(c.y, d.y));
+    const int X1 = max(max(a.z, b.z), max(c.z, d.z)), Y1 = max(max(a.w, b.w), max(c.w, d.w));
     w.ww = X1 - w.X0;
     w.area = (X1 > w.X0 && Y1 > w.Y0) ? w.ww * (Y1 - w.Y0) : 0;
     w.fits = w.area > 0 && w.area <= kHistBins;
@@ -384,12 +428,10 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     const int x1 = (SAS_TUNE_PABL & 16) ? min(g.x1, g.x0 + 1) : g.x1, y1 = (SAS_TUNE_PABL & 16) ? min(g.y1, g.y0 + 1) : g.y1;   // (16: one tile per Gaussian)
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
-    const Window w = wg_window(in_win, x0, x1, y0, y1, s_win);
+    const Window w = wg_window_zeroed(in_win, x0, x1, y0, y1, s_win, s_hist);   // (the bins are zero behind its barrier)
     PL_LAP(1);
     unsigned long long reached = 0ull;   // the tiles of the rectangle that were counted (kept for the emit pass)
     if (w.fits) {
-        for (int b = threadIdx.x; b < w.area; b += 256) s_hist[b] = 0;
-        __syncthreads();
         if (in_win) {
             int k = 0;   // tile k of the rectangle, row by row (at most kWinRect = 64 of them: one mask bit each)
             for (int ty = y0; ty < y1; ++ty) {
@@ -459,39 +501,46 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
                       [&](int tile, unsigned, unsigned) { if (SAS_IN(tile, f.n_tiles, 103)) atomicAdd(&f.tile_big[tile], 1); });
     }
     PL_LAP(5);
-    // visible count: one plain store per workgroup (a same-address atomic per wave would
-    // serialise at ~90 atomics/us); the projection's tail adds the per-workgroup counts up
-    if (threadIdx.x == 0) { s_nvis[0] = 0; s_nvis[1] = 0; }
-    __syncthreads();
+    // visible count (and the contract's 16-pixel intersections where the lists are not T3's).
     const unsigned long long vb = __ballot(vis);
-    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis[0], (int)__popcll(vb));
+    int a16 = 0;
     if (f.wg_isect16) {   // (uniform) 8-pixel binning, culled lists: the frame still reports the intersections with the contract's 16-pixel tiles
-        int a16 = !vis ? 0 : tile_px == 8 ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : rect_area;
+        a16 = !vis ? 0 : tile_px == 8 ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : rect_area;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) a16 += __shfl_xor(a16, d);
-        if ((threadIdx.x & 63) == 0 && a16) atomicAdd(&s_nvis[1], a16);
     }
-    __syncthreads();
     // HAND-OFF RULE (projection workgroups -> the tail, possibly on another XCD, whose L2 is not coherent with this one):
     // everything the tail reads from other workgroups must be written by an AGENT-scope atomic (performed where all XCDs
-    // see it): the per-tile counts (atomicAdd on tile_count / tile_big), the window-miss counter, and these stores through
-    // agent_store().  A plain store here -- e.g. a vectorised store of counts -- would sit in this XCD's L2 and reach the
-    // tail stale, silently; the bounds build checks the rule's effect (scan_tail: the sum of wg_vis against a counter that
-    // every workgroup also adds its count to atomically).
-    if (threadIdx.x == 0 && seg > 0) {
-        // single-pass frames: the sums ride on the workgroup's ticket line (words 1, 2), where the tail's first wave finds all of them
-        unsigned *tk = f.tickets + 32u * (wg & 63u);
-        if (s_nvis[0]) atomicAdd(&tk[1], (unsigned)s_nvis[0]);
-        if (f.wg_isect16 && s_nvis[1]) atomicAdd(&tk[2], (unsigned)s_nvis[1]);
+    // see it): the per-tile counts (atomicAdd on tile_count / tile_big), the window-miss counter, and the sums below.
+    // A plain store here -- e.g. a vectorised store of counts -- would sit in this XCD's L2 and reach the
+    // tail stale, silently; the bounds build checks the rule's effect (the tail: the sum it collects against a counter that
+    // every wave also adds its count to atomically).
+    if (seg > 0) {
+        // single-pass frames: every WAVE adds its sums to words 1 and 2 of the workgroup's ticket line (64 lines, ~240 adds
+        // each per frame: far from the rate at which one address serialises), where the tail's first wave finds all of them --
+        // no LDS round, no barrier (the two barriers of a per-workgroup sum cost a geometry workgroup 1.2 of its 17 us)
+        if ((threadIdx.x & 63) == 0) {
+            unsigned *tk = f.tickets + 32u * (wg & 63u);
+            if (vb) atomicAdd(&tk[1], (unsigned)__popcll(vb));
+            if (a16) atomicAdd(&tk[2], (unsigned)a16);
 #ifdef SAS_DEBUG_BOUNDS
-        atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);
+            if (vb) atomicAdd(&f.stats[6], (unsigned)__popcll(vb));
 #endif
-    } else if (threadIdx.x == 0) {
-        agent_store(&f.wg_vis[wg], s_nvis[0]);
-        if (f.wg_isect16) agent_store(&f.wg_isect16[wg], s_nvis[1]);
+        }
+    } else {
+        // two-pass frames: one plain (agent-scope) store per workgroup; their tail adds the per-workgroup counts up
+        if (threadIdx.x == 0) { s_nvis[0] = 0; s_nvis[1] = 0; }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&s_nvis[0], (int)__popcll(vb));
+        if ((threadIdx.x & 63) == 0 && a16) atomicAdd(&s_nvis[1], a16);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            agent_store(&f.wg_vis[wg], s_nvis[0]);
+            if (f.wg_isect16) agent_store(&f.wg_isect16[wg], s_nvis[1]);
 #ifdef SAS_DEBUG_BOUNDS
-        atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);   // (bounds build only) the same count through a device atomic: the tail compares
+            atomicAdd(&f.stats[6], (unsigned)s_nvis[0]);   // (bounds build only) the same count through a device atomic: the tail compares
 #endif
+        }
     }
     PL_LAP(6);
 }
@@ -997,8 +1046,8 @@ DEV void geom_role(const SasScene &s, const SasCam &c, const SasFrame &f, unsign
         }
         if (g.vis) {
             if (!(SAS_TUNE_PABL & 8)) {
-                f.rec[2 * i + 0] = make_float4(g.mx, g.my, g.ca, g.cb);
-                f.rec[2 * i + 1] = make_float4(g.ccn, op, g.thr, g.z);
+                f.rec[SAS_RS * i + 0] = make_float4(g.mx, g.my, g.ca, g.cb);
+                f.rec[SAS_RS * i + 1] = make_float4(g.ccn, op, g.thr, g.z);
                 // radii (parity hook only): full 32 bits each (a camera inside the cloud produces radii beyond 65535
                 // pixels); saturated to INT_MAX
                 const int irx = (int)fminf(g.rx, 2147483520.0f), iry = (int)fminf(g.ry, 2147483520.0f);
@@ -1094,8 +1143,10 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
         const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
         sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
     }
+    // (one view after the other: the scheduling barrier keeps the compiler from interleaving the two evaluations, which costs registers)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+        if (v > 0) __builtin_amdgcn_sched_barrier(0);
         if (!ok[v]) continue;
         const SasCam &c = vs.cam[v];
         float rgb[3];
@@ -1104,7 +1155,7 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
         } else {
             rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
         }
-        if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+        if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
     }
 #ifdef SAS_TUNE_PTIME
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (instrumented build: the stamp is taken when the stores have been acknowledged)
@@ -1147,7 +1198,7 @@ DEV Role block_role(unsigned b, unsigned n_geo, unsigned mix_k)
 template <int DEG, int NV>
 __global__ SAS_PROJECT_ATTRS void k_project(SasScene s, ProjArgs vs)
 {
-    __shared__ int s_win[4];
+    __shared__ __attribute__((aligned(16))) int s_win[16];
     __shared__ __attribute__((aligned(16))) int s_bins2[2 * kHistBins];   // one block: the tail uses all 16 KiB of it
     int *const s_hist = s_bins2;
     int *const s_base = s_bins2 + kHistBins;   // single-pass binning: start of the workgroup's run inside each window tile's segment
@@ -1175,7 +1226,7 @@ __global__ SAS_PROJECT_ATTRS void k_project(SasScene s, ProjArgs vs)
 template <int DEG>
 __global__ __launch_bounds__(256) void k_project_multi(SasScene s, SasMulti mf)
 {
-    __shared__ int s_win[4];
+    __shared__ __attribute__((aligned(16))) int s_win[16];
     __shared__ __attribute__((aligned(16))) int s_bins2[2 * kHistBins];
     int *const s_hist = s_bins2;
     int *const s_base = s_bins2 + kHistBins;
@@ -1293,7 +1344,7 @@ DEV void scatter_body(const SasScene &s, int tw, const SasFrame &f)
     if (i < s.n) inf = f.info[i];
     const int x0 = inf.x & 0xffff, x1 = inf.x >> 16, y0 = inf.y & 0xffff, y1 = inf.y >> 16;
     const bool vis = x1 > x0 && y1 > y0;
-    const unsigned zbits = vis ? __float_as_uint(f.rec[2 * i + 1].w) : 0u;   // (info holds the rectangle and the radii; the depth is the record's)
+    const unsigned zbits = vis ? __float_as_uint(f.rec[SAS_RS * i + 1].w) : 0u;   // (info holds the rectangle and the radii; the depth is the record's)
     const unsigned long long key = ((unsigned long long)zbits << 32) | (unsigned long long)(unsigned)i;
     const int rect_area = vis ? (x1 - x0) * (y1 - y0) : 0;
     const bool in_win = rect_area > 0 && rect_area <= kWinRect;
@@ -1371,7 +1422,7 @@ static int project_mix(int nv, unsigned n_wg)
     static const int env = [] { const char *e = getenv("SAS_PROJ_MIX"); return e ? atoi(e) : 0; }();
     const unsigned n_geo = (unsigned)nv * sas_spread_blocks(n_wg), total = n_geo + n_wg;
     const int kmin = (int)((8u * n_geo + total - 1u) / total);
-    const int k = env > 0 ? env : (nv == 1 ? 6 : 7);
+    const int k = env > 0 ? env : (nv == 1 ? 5 : 7);
     return k < kmin ? kmin : (k > 8 ? 8 : k);
 }
 

@@ -620,9 +620,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         if (have) {
             long long id = slot_at(idx);
             if (!SAS_IN(id, n_gauss, 201) || id >= n_gauss) id = n_gauss - 1;   // never dereference a bad index
-            ra = f.rec[2 * id + 0];
-            rb = f.rec[2 * id + 1];
-            rc = f.col[id];
+            ra = f.rec[SAS_RS * id + 0];
+            rb = f.rec[SAS_RS * id + 1];
+            rc = f.col[SAS_CS * id];
 #ifdef SAS_TUNE_STATS
             dbg_rx = f.info[id].z;
             dbg_ry = f.info[id].w;
@@ -885,9 +885,9 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
             id &= 1023;   // timing experiment: the records come from 48 KiB that stay in the caches (wrong images)
 #endif
             if (!SAS_IN(id, n_gauss, 231) || id >= n_gauss) id = n_gauss - 1;
-            ra = f.rec[2 * id + 0];
-            rb = f.rec[2 * id + 1];
-            rc = f.col[id];
+            ra = f.rec[SAS_RS * id + 0];
+            rb = f.rec[SAS_RS * id + 1];
+            rc = f.col[SAS_CS * id];
         }
     };
     if (count > 0) fetch(0);
@@ -1494,7 +1494,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                 for (int i = tid; i < cnt_chunk; i += kLazyThreads) {
                     if (!SAS_IN(st + i, n, 216) || !SAS_IN(i, CH, 217)) continue;
                     const unsigned slot = (unsigned)ids[st + i];
-                    const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? __float_as_uint(f.rec[2 * (long long)slot + 1].w) : dmin;
+                    const unsigned dbits = SAS_IN(slot, n_gauss, 218) ? __float_as_uint(f.rec[SAS_RS * (long long)slot + 1].w) : dmin;
                     ck[i] = ((unsigned long long)(dbits - base) << 32) | slot;
                 }
             }

@@ -54,6 +54,8 @@ class FrameGather:
         self.collective = world > 1 if collective is None else bool(collective)
         self._work = None
         self._bufs: Optional[List[torch.Tensor]] = None
+        if self.collective and not dist.is_initialized():
+            raise RuntimeError("FrameGather(collective=True) needs an initialised torch.distributed process group (init_from_env)")
         self._via_host = self.collective and dist.get_backend() == "gloo"   # gloo cannot gather device tensors
 
     def start(self, frame: torch.Tensor):
@@ -93,7 +95,7 @@ class StepPipeline:
     def __init__(self, world: int, rank: int, buffers: Sequence, submit, steps_completed, wait, payload=lambda b: b,
                  on_gathered=None, collective: Optional[bool] = None):
         if len(buffers) < 2:
-            raise ValueError("need at least two buffers")
+            raise ValueError("need at least two buffers (entries may be None when every step brings its own: set_buffer)")
         self.world, self.rank = world, rank
         self.bufs = list(buffers)
         self._submit, self._completed, self._wait, self._payload = submit, steps_completed, wait, payload

@@ -132,22 +132,33 @@ class _Dataset:
         return len(self.cameras)
 
     def get_image_float32(self, image_idx: int) -> torch.Tensor:
-        """The training / eval image ``image_idx`` as float32 ``[H,W,3]`` in 0..1 (nerfstudio's
-        ``InputDataset.get_image_float32``: the file read as uint8, divided by 255, an alpha channel blended onto
-        black... which is what the reference's ``get_images`` collects, nerfstudio_utils.py:101-111).  The images
-        are the capture a run was trained on; the reference's assets do not ship them (only ``transforms.json``
-        names them), so a missing file raises ``FileNotFoundError`` naming the path expected."""
+        """The training / eval image ``image_idx`` as float32 in 0..1, as nerfstudio 1.1.5's ``InputDataset.get_image_float32``
+        returns it (restated from public knowledge; the reference's ``get_images`` collects these, nerfstudio_utils.py:101-111):
+        the file read as uint8 (resized bilinearly by the dataset's ``scale_factor`` when that is not 1), a grey image repeated
+        to three channels, divided by 255; an alpha channel is blended onto the dataparser's ``alpha_color`` ONLY when the
+        dataparser sets one -- the ``nerfstudio`` dataparser of the reference's runs does not, so an RGBA file comes back with
+        its four channels ``[H,W,4]``.  The images are the capture a run was trained on; the reference's assets do not ship
+        them (only ``transforms.json`` names them), so a missing file raises ``FileNotFoundError`` naming the path expected."""
         f = self._dataparser_outputs.image_filenames[image_idx]
         if not Path(f).is_file():
             raise FileNotFoundError(f"{f}: image {image_idx} of the run's dataset is not on disk (the reference's assets ship "
                                     f"transforms.json and the run, not the captured images)")
         from PIL import Image
-        img = np.asarray(Image.open(f), dtype=np.uint8)
+        pil = Image.open(f)
+        scale = float(getattr(self, "scale_factor", 1.0))
+        if scale != 1.0:
+            w, h = pil.size
+            pil = pil.resize((int(w * scale), int(h * scale)), resample=Image.BILINEAR)
+        img = np.asarray(pil, dtype=np.uint8)
         if img.ndim == 2:
             img = img[:, :, None].repeat(3, axis=2)
+        if img.shape[2] not in (3, 4):
+            raise ValueError(f"{f}: image shape {img.shape} is not [H,W,3] or [H,W,4]")
         x = torch.from_numpy(img.astype(np.float32) / 255.0)
-        if x.shape[-1] == 4:
-            x = x[:, :, :3] * x[:, :, 3:4]
+        alpha_color = getattr(self._dataparser_outputs, "alpha_color", None)
+        if alpha_color is not None and x.shape[-1] == 4:
+            ac = torch.as_tensor(alpha_color, dtype=torch.float32)
+            x = x[:, :, :3] * x[:, :, -1:] + ac * (1.0 - x[:, :, -1:])
         return x
 
 

@@ -229,10 +229,12 @@ class SplatScene:
             return self._raster.render_cameras_host(qp[0], qp[1, :, :3], f, int(width), int(height), self.background).numpy()
 
     def get_renders_posed(self, height: int, width: int, cam_poses, pose_sets, pose_set, fov: Optional[float] = None,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, device_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """uint8 [C,H,W,3] (pinned host tensor) for C same-sized cameras of SEVERAL envs in one call: view v is rendered
         with the group poses ``pose_sets[pose_set[v]]`` ([S,G,12] float32; vectorised envs, sas_render_batch_host_posed)
-        instead of the scene's current ones; ``out`` supplies the tensor."""
+        instead of the scene's current ones; ``out`` supplies the tensor.  ``device_out`` (a uint8 [C,H,W,3] tensor on the
+        scene's GPU) keeps the frames ON THE DEVICE instead (sas_render_batch_posed): what a multi-GPU rollout gathers
+        over RCCL without the frames ever visiting the host on the way."""
         f = self.camera.fov if fov is None else float(fov)
         C = len(cam_poses)
         q, p = np.empty((C, 4), np.float64), np.empty((C, 3), np.float64)
@@ -241,6 +243,9 @@ class SplatScene:
         V, K = self._views_and_Ks(int(height), int(width), q, p, f)
         with self.lock:
             self._sync()
+            if device_out is not None:
+                return self._raster.render_batch(V, K, int(width), int(height), self.background, want=("rgb8",), out={"rgb8": device_out},
+                                                 pose_sets=pose_sets, pose_set=pose_set)["rgb8"]
             return self._raster.render_batch_host(V, K, int(width), int(height), self.background, out=out, pose_sets=pose_sets, pose_set=pose_set)
 
     def attached_frame(self, q_link, p_link, local_xyz, owner=None):

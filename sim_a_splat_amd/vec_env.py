@@ -18,6 +18,11 @@ library object (round 3 had it only as a loop inside bench.py):
 * the uint8 frames (``camera_i`` observations, splat_env_wrapper.py:135-137) of all ranks are gathered to
   rank 0 through ``distributed.StepPipeline`` (backend ``nccl`` = RCCL on a multi-GPU node, ``gloo`` in
   the CPU tests); the small non-image observations, rewards and flags travel as objects beside them.
+  On the ``nccl`` backend the frames stay DEVICE-RESIDENT until they are on rank 0: rendered into a device
+  buffer (``sas_render_batch_posed``), gathered over xGMI as they are, copied to pinned host memory once, on the
+  root (round 4 rendered to the host and uploaded the frames again as the gather's payload: host -> device ->
+  xGMI -> device -> host; ``h2d_frame_copies`` counts such uploads and stays 0 now).  A single rank, the other
+  ranks' own frames and ``gloo`` keep the host path (the tile kernel stores the frames to pinned memory itself).
 
 SPMD calling convention: every rank constructs the same ``SplatVecEnv`` and calls ``reset`` / ``step``
 with the actions of ALL envs; a rank applies those of its own envs.  Rank 0 gets the observations of
@@ -63,24 +68,46 @@ class SplatVecEnv:
         self.fov = fov
         self.per_rank = (self.E + self.world - 1) // self.world          # envs per rank, padded: one gather shape for all
         self._collective = (self.world > 1) if collective is None else bool(collective)
-        self._via_host = True                                            # frames land in pinned host memory (Door B's uint8 arrays)
+        if self._collective and not dist.is_initialized():
+            raise RuntimeError("SplatVecEnv(collective=True) gathers through torch.distributed: initialise the process group first "
+                               "(sim_a_splat_amd.distributed.init_from_env)")
         self._msgs: List = [None] * self.E
         self._pin: Optional[bool] = None
-        self._bufs = [self._new_buffer() for _ in range(3)]               # a ring: at most two steps outstanding
+        # RCCL gathers device tensors: there the frames are rendered into DEVICE buffers and travel as they are
+        self._device_payload = self._collective and dist.get_backend() == "nccl"
+        self._device = getattr(getattr(self.scene, "_raster", None), "device", None) if self._device_payload else None   # the scene's GPU
+        if self._device_payload and self._device is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        self.h2d_frame_copies = 0                                         # uploads of finished frames (the nccl arm must not need any)
+        self.d2h_frame_copies = 0                                         # downloads of gathered / own device frames (one per step and rank that consumes them)
+        self._bufs = [None, None, None]                                   # a ring of three steps: every step brings a buffer of its own (_submit)
         self._pending: Dict[int, Tuple] = {}                              # step index -> what travels beside its frames
         self._gathered: Dict[int, Optional[List[torch.Tensor]]] = {}
         self._step_idx = 0
         self._done_steps = 0
-        self._device_payload = self._collective and dist.is_initialized() and dist.get_backend() == "nccl"
         self._pipe = D.StepPipeline(self.world, self.rank, self._bufs, self._submit, lambda: self._done_steps, lambda: None,
                                     payload=self._payload, on_gathered=self._on_gathered, collective=self._collective)
         self._pipe.begin()
 
     # -- buffers -----------------------------------------------------------------------------------------------
     def _new_buffer(self) -> torch.Tensor:
-        """A frame buffer of this rank's envs (pinned: the tile kernel stores the frames into it; torch's caching host
-        allocator hands recently freed blocks back, so a buffer per step costs no allocation in steady state)."""
+        """A frame buffer of this rank's envs: pinned host memory (the tile kernel stores the frames into it), or device
+        memory on the nccl arm.  torch's caching allocators hand recently freed blocks back, so a buffer per step costs no
+        allocation in steady state.  Rows beyond this rank's envs (E % world != 0, a rank without envs) are padding of the
+        gather's common shape: zeroed, not whatever the block held."""
         shape = (self.per_rank * self.C, self.H, self.W, 3)
+        n_mine = len(self.mine) * self.C
+        if self._device_payload:
+            buf = torch.empty(shape, dtype=torch.uint8, device=self._device)
+            if n_mine < shape[0]:
+                buf[n_mine:].zero_()
+            return buf
+        buf = self._new_host_buffer(shape)
+        if n_mine < shape[0]:
+            buf[n_mine:].zero_()
+        return buf
+
+    def _new_host_buffer(self, shape) -> torch.Tensor:
         if self._pin is None:                                             # asked once: torch.cuda.is_available() costs 0.4 ms a call
             self._pin = bool(torch.cuda.is_available())
         try:
@@ -90,9 +117,21 @@ class SplatVecEnv:
             return torch.empty(shape, dtype=torch.uint8)
 
     def _payload(self, buf: torch.Tensor) -> torch.Tensor:
-        # RCCL gathers device tensors: the rank's frames go back up once (6 MB per 8 envs x 2 cameras of 240x320: the
-        # transfer a multi-GPU node trades for rendering E / world envs per GPU); gloo takes the host buffer as it is
-        return buf.cuda(non_blocking=True) if self._device_payload else buf
+        # what the gather moves IS the buffer the frames were rendered into: device memory under RCCL, host memory under gloo
+        if self._device_payload and not buf.is_cuda:                      # (cannot happen with _new_buffer's buffers; counted if it ever does)
+            self.h2d_frame_copies += 1
+            return buf.cuda(non_blocking=True)
+        return buf
+
+    def _to_host(self, frames: torch.Tensor) -> torch.Tensor:
+        """Finished frames for the caller (np.uint8 observations live on the host): device frames come down once, into pinned memory."""
+        if not frames.is_cuda:
+            return frames
+        host = self._new_host_buffer(tuple(frames.shape))
+        host.copy_(frames, non_blocking=True)
+        torch.cuda.current_stream(frames.device).synchronize()
+        self.d2h_frame_copies += 1
+        return host
 
     # -- the per-step work of a rank ------------------------------------------------------------------------------
     def _pose_set_of(self, msg) -> np.ndarray:
@@ -115,12 +154,22 @@ class SplatVecEnv:
             flat = [c for env_c in cams for c in env_c]
             idx = [k for k in range(len(msgs)) for _ in range(self.C)]
             n = len(flat)
-            self.scene.get_renders_posed(self.H, self.W, flat, pose_sets, idx, fov=self.fov, out=buf[:n])
+            if self._device_payload:
+                self.scene.get_renders_posed(self.H, self.W, flat, pose_sets, idx, fov=self.fov, device_out=buf[:n])
+            else:
+                self.scene.get_renders_posed(self.H, self.W, flat, pose_sets, idx, fov=self.fov, out=buf[:n])
         self._done_steps += 1
 
     def _on_gathered(self, step: int, got) -> None:
-        # (the gather's receive buffers are reused by the next step: the observations are views of copies)
-        self._gathered[step] = None if got is None else [g.cpu() if g.is_cuda else g.clone() for g in got]
+        # (the gather's receive buffers are reused by the next step: the observations are views of copies.)  Device frames --
+        # the RCCL arm -- come down here, on the root, once per step: all ranks' blocks through one pinned buffer
+        if got is None:
+            self._gathered[step] = None
+        elif got[0].is_cuda:
+            host = self._to_host(torch.stack(list(got)) if len(got) > 1 else got[0].unsqueeze(0))
+            self._gathered[step] = [host[r] for r in range(len(got))]
+        else:
+            self._gathered[step] = [g.clone() for g in got]
 
     # -- Gym surface ---------------------------------------------------------------------------------------------
     def _u(self, e: int):
@@ -171,13 +220,16 @@ class SplatVecEnv:
         obs = self._assemble(ticket, inner)
         return (obs, *self._exchange_extra(extra))
 
-    def close(self) -> None:
+    def close(self, close_scene: bool = True) -> None:
+        """Drain the pipeline and close this rank's envs.  The scene belongs to the caller's handler; it is closed with the
+        vectorised env unless ``close_scene=False`` (a caller that goes on using the handler)."""
         self._pipe.drain()
         for e in self.mine:
             c = getattr(self._u(e), "close", None)
             if c:
                 c()
-        self.scene.close()
+        if close_scene:
+            self.scene.close()
 
     # -- internals -----------------------------------------------------------------------------------------------
     def _step_physics(self, actions):
@@ -208,7 +260,7 @@ class SplatVecEnv:
                 for k, e in enumerate(D.shard_views(self.E, r, self.world)):
                     frames_of[e] = got[r][k * self.C:(k + 1) * self.C]
         else:                                                              # a single rank, or a rank that is not the root: its own envs
-            buf = self._pipe.buffer_of(t)
+            buf = self._to_host(self._pipe.buffer_of(t))
             for k, e in enumerate(self.mine):
                 frames_of[e] = buf[k * self.C:(k + 1) * self.C]
         all_inner = self._exchange_objects(inner)

@@ -26,4 +26,6 @@ def test_rccl_gathers_device_frames_at_world_size_one():
     assert line["backend"] == "nccl" and line["world"] == 1 and line["device_tensors"]
     assert line["pipeline_bit_equal"] and line["gather_frames_bit_equal"] and line["float_frame_bit_equal"], line
     assert line["vec_env_bit_equal"], line      # SplatVecEnv's observations gathered through RCCL == its single-process ones
+    # ... and its frames never bounce through the host on the way: no upload of a finished frame, one download per step on the root
+    assert line["vec_env_device_resident"], line
     print("RCCL", line["rccl_version"], line)

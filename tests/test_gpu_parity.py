@@ -1055,16 +1055,28 @@ def test_exact_tile_culling_changes_no_pixel(monkeypatch, quad):
     inside = make_scene(50_000, seed=44, log_scale_mean=float(np.log(0.02)))
     cam_in = ring_camera(400, 304, 250.0, radius=0.2)
     scenes.append((inside, cam_in))
-    keys = {}
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+    from tile_cull_model import kept_pairs
+    import oracle
+    keys, model = {}, {}
     for cull in ("1", "0"):
         monkeypatch.setenv("SAS_CULL", cull)
         r = Rasterizer("cuda:0")
         try:
             for i, (sc, cam) in enumerate(scenes):
                 _upload(r, sc)
-                _compare(r, sc, cam, depth_fill=True)
+                _, ref = _compare(r, sc, cam, depth_fill=True)
                 st = r.stats()
                 keys[(cull, i)] = (st["n_keys"], st["n_isect"])
+                if cull == "1" and quad == "0":
+                    # the EXACT number of keys the kernel may bin: the NumPy restatement of its test (tests/tools/tile_cull_model.py,
+                    # operation for operation) on the oracle's projection of the same view
+                    o = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats,
+                                      scales=sc.scales, sh_degree=3, dump=True)
+                    n_rect, keep, *_ = kept_pairs(o, sc.opacities, cam.width, cam.height, oracle.logf)
+                    model[i] = (n_rect, int(keep.sum()))
         finally:
             r.close()
     for i in range(len(scenes)):
@@ -1073,6 +1085,8 @@ def test_exact_tile_culling_changes_no_pixel(monkeypatch, quad):
         assert on[0] < off[0], (i, on, off)         # and shorter lists
         if quad == "0":
             assert off[0] == off[1]
+            # an over-cull that happened to leave these images unchanged, or a drift between the kernel and its model, shows here
+            assert model[i] == (on[1], on[0]), (i, model[i], on)
 
 
 def test_segment_sizing_follows_the_frame(monkeypatch):

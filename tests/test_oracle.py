@@ -263,7 +263,7 @@ def test_tile_culling_criterion_drops_only_tiles_no_pixel_of_which_is_reached():
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
-    from tile_cull_model import tile_reached
+    from tile_cull_model import kept_pairs
     from sim_a_splat_amd.synthetic import make_scene, ring_camera
     rng = np.random.default_rng(5)
     plain = make_scene(30_000, seed=41, log_scale_mean=float(np.log(0.012)))
@@ -273,21 +273,12 @@ def test_tile_culling_criterion_drops_only_tiles_no_pixel_of_which_is_reached():
     for sc, cam, min_rate in ((plain, ring_camera(640, 480, 525.0), 0.10), (needles, ring_camera(333, 251, 300.0, yaw_deg=40.0), 0.0)):
         o = oracle.render(sc.means, sc.opacities, sc.sh, cam.viewmat, cam.K, cam.width, cam.height, quats=sc.quats,
                           scales=sc.scales, sh_degree=3, dump=True)
+        n_rect, keep, rep, tx, ty = kept_pairs(o, sc.opacities, cam.width, cam.height, oracle.logf)
+        assert n_rect == o["n_isect"]          # T3's rectangles, as the oracle counts them
         idx = np.nonzero((o["radii"] > 0).all(axis=1))[0]
         mx, my = o["means2d"][idx, 0], o["means2d"][idx, 1]
         A, B, C = (o["conics"][idx, k] for k in range(3))
         op = np.asarray(sc.opacities, np.float32).reshape(-1)[idx]
-        thr = np.array([oracle.logf(float(np.float32(255.0) * v)) for v in op], np.float32) + np.float32(1e-3)   # (project_view: lnq + 1e-3)
-        tw, th = (cam.width + 15) // 16, (cam.height + 15) // 16
-        rx, ry = o["radii"][idx, 0].astype(np.float32), o["radii"][idx, 1].astype(np.float32)
-        x0 = np.clip(np.floor((mx - rx) / 16), 0, tw).astype(np.int64); x1 = np.clip(np.ceil((mx + rx) / 16), 0, tw).astype(np.int64)
-        y0 = np.clip(np.floor((my - ry) / 16), 0, th).astype(np.int64); y1 = np.clip(np.ceil((my + ry) / 16), 0, th).astype(np.int64)
-        w, area = x1 - x0, (x1 - x0) * (y1 - y0)
-        assert int(area.sum()) == o["n_isect"]          # T3's rectangles, as the oracle counts them
-        rep = np.repeat(np.arange(len(idx)), area)
-        k = np.arange(int(area.sum())) - (np.cumsum(area) - area)[rep]
-        tx, ty = x0[rep] + k % w[rep], y0[rep] + k // w[rep]
-        keep = tile_reached(mx[rep], my[rep], A[rep], B[rep], C[rep], thr[rep], tx, ty)
         drop = np.nonzero(~keep)[0]
         assert len(drop) >= min_rate * len(rep), (len(drop), len(rep))
         # brute force over the 256 pixel centres of every rejected tile, float64

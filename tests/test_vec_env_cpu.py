@@ -126,6 +126,30 @@ def test_single_rank_steps_and_async_steps():
     assert all(env.closed for env in venv.envs)
 
 
+def test_collective_without_a_process_group_is_a_clear_error_and_padding_rows_are_zero():
+    """ADVICE (round 4): ``collective=True`` with no torch.distributed process group used to fail inside ``dist.get_backend()``;
+    rows of a rank's buffer beyond its own envs (the gather's common shape) were whatever the allocator handed out; ``close``
+    closed the caller's scene unconditionally."""
+    from sim_a_splat_amd import distributed as D
+    assert not dist.is_initialized()
+    with pytest.raises(RuntimeError, match="process group"):
+        _build(0, 1, 3, collective=True)
+    with pytest.raises(RuntimeError, match="process group"):
+        D.FrameGather(1, 0, collective=True)
+    venv, h = _build(1, 2, 5, collective=False)          # rank 1 of 2 owns envs 1 and 3: two of its three rows
+    assert venv.mine == [1, 3] and venv.per_rank == 3
+    venv.reset(seed=3)
+    buf = venv._pipe.buffer_of(0)
+    assert buf.shape[0] == 3 * venv.C and int(buf[2 * venv.C:].max()) == 0 and int(buf[:2 * venv.C].max()) > 0
+    assert venv.h2d_frame_copies == 0 and venv.d2h_frame_copies == 0      # host frames: nothing to move
+    closed = []
+    h.scene.close = lambda: closed.append(True)
+    venv.close(close_scene=False)
+    assert not closed
+    venv.close()
+    assert closed == [True]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -93,10 +93,15 @@ for step in range(3):
             vec_ok = vec_ok and bool(np.array_equal(a[e][f"camera_{c}"], b[e][f"camera_{c}"]))
             seen = max(seen, int(a[e][f"camera_{c}"].max()))
 vec_ok = vec_ok and seen > 0          # (the viewport camera looks at the scene; the link camera may not)
+# the RCCL arm keeps the frames on the device until they are on the root: rendered into device buffers, gathered as they
+# are, ONE download per step on rank 0 -- no finished frame is ever uploaded (round 4: host -> device -> xGMI -> device -> host)
+vec_device_resident = via_rccl._device_payload and via_rccl.h2d_frame_copies == 0 and via_rccl.d2h_frame_copies == 3 \
+    and plain.h2d_frame_copies == 0 and plain.d2h_frame_copies == 0
 
 ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else "?"
 print(json.dumps({"backend": dist.get_backend(), "world": world, "rccl_version": ver, "steps": STEPS, "views_per_step": V,
                   "pipeline_bit_equal": bool(pipeline_ok), "gather_frames_bit_equal": bool(helper_ok), "float_frame_bit_equal": bool(float_ok),
-                  "vec_env_bit_equal": bool(vec_ok), "device_tensors": True}))
+                  "vec_env_bit_equal": bool(vec_ok), "vec_env_device_resident": bool(vec_device_resident),
+                  "vec_env_copies": {"h2d": via_rccl.h2d_frame_copies, "d2h": via_rccl.d2h_frame_copies}, "device_tensors": True}))
 r.close()
 dist.destroy_process_group()

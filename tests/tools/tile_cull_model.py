@@ -37,3 +37,24 @@ def tile_reached(mx, my, ca, cb, cc, thr, tx, ty, px=16.0):
     q2 = fma(bdyc, dxs, s2)
     m2 = fma(np.full_like(s2, -2e-5), s2, q2)
     return ~((m1 > lim) & (m2 > lim))
+
+
+def kept_pairs(o, opacities, width, height, logf):
+    """From an oracle dump `o` (radii, means2d, conics of every Gaussian; sas_oracle dump=True): T3's rectangle pairs and which
+    of them `tile_reached` keeps at 16-pixel binning.  Returns (n_rect, keep[bool per pair], rep[Gaussian per pair], tx, ty).
+    `logf`: the contract logarithm (oracle.logf)."""
+    idx = np.nonzero((o["radii"] > 0).all(axis=1))[0]
+    mx, my = o["means2d"][idx, 0], o["means2d"][idx, 1]
+    A, B, C = (o["conics"][idx, k] for k in range(3))
+    op = np.asarray(opacities, np.float32).reshape(-1)[idx]
+    thr = np.array([logf(float(np.float32(255.0) * v)) for v in op], np.float32) + np.float32(1e-3)   # (project_view: lnq + 1e-3)
+    tw, th = (width + 15) // 16, (height + 15) // 16
+    rx, ry = o["radii"][idx, 0].astype(np.float32), o["radii"][idx, 1].astype(np.float32)
+    x0 = np.clip(np.floor((mx - rx) / 16), 0, tw).astype(np.int64); x1 = np.clip(np.ceil((mx + rx) / 16), 0, tw).astype(np.int64)
+    y0 = np.clip(np.floor((my - ry) / 16), 0, th).astype(np.int64); y1 = np.clip(np.ceil((my + ry) / 16), 0, th).astype(np.int64)
+    w, area = x1 - x0, (x1 - x0) * (y1 - y0)
+    rep = np.repeat(np.arange(len(idx)), area)
+    k = np.arange(int(area.sum())) - (np.cumsum(area) - area)[rep]
+    tx, ty = x0[rep] + k % np.maximum(w[rep], 1), y0[rep] + k // np.maximum(w[rep], 1)
+    keep = tile_reached(mx[rep], my[rep], A[rep], B[rep], C[rep], thr[rep], tx, ty)
+    return int(area.sum()), keep, rep, tx, ty
