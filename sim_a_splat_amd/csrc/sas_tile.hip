@@ -1672,6 +1672,7 @@ template <bool FAST, bool WMAX>
 static void launch_blend_list(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n,
                               const int *tl, const int *range)
 {
+
     hipLaunchKernelGGL((k_blend<FAST, WMAX>), dim3(grid), dim3(256), 0, st, P, f, n, tl, range);
 }
 
