@@ -659,7 +659,13 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #endif
         if (every_done) { all_done = true; break; }
         unsigned ment = 0u;
-        if (have) ment = block_mask16(tx, ty, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+        {
+            // (the tile's coordinates, opaque per batch: hipcc otherwise hoists block_mask16's eight block-centre coordinates out of
+            // the tile's loops and, short of registers, parks them in scratch -- eight reloads with a full vmcnt wait per batch)
+            int txo = tx, tyo = ty;
+            asm volatile("" : "+s"(txo), "+s"(tyo));
+            if (have) ment = block_mask16(txo, tyo, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
+        }
 #ifdef SAS_TUNE_STATS
         DBG_ADD(12, __popcll(__ballot(have && ment == 0u)));
         DBG_ADD(13, __popcll(__ballot(have)));
@@ -714,6 +720,10 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             // of the batch loop and spills them (16 scratch reloads per batch, each with a full vmcnt wait)
             unsigned lane16 = (unsigned)lane << 4;
             asm volatile("" : "+v"(lane16));
+            // bit of the wave's block 0 in the entry masks, opaque per batch (hipcc otherwise keeps the four masks 1 << bit alive
+            // across the tile's loops and spills them: sixteen scratch reloads per batch)
+            unsigned bit0 = (unsigned)((wv & 1) * 2 + 8 * (wv >> 1));
+            asm volatile("" : "+v"(bit0));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (64 * j >= cnt) break;   // partial batch (uniform)
@@ -721,7 +731,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 const unsigned me = e < cnt ? L.mask[e] : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int bit = ((wv & 1) * 2 + (g & 1)) + 4 * ((wv >> 1) * 2 + (g >> 1));
+                    const unsigned bit = bit0 + (unsigned)((g & 1) + 4 * (g >> 1));
                     const bool has = (me >> bit) & 1u;
                     const unsigned long long m = __ballot(has);
                     const int below = (int)mbcnt64(m);
@@ -1030,7 +1040,11 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
 }
 
 // T0 epilogue for this thread's pixel; returns its expected depth (0 outside the image).
-DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W, unsigned &rgb8_packed)
+// pack4 (uniform; the ordinary layout, image width and rgb8 base multiples of four): lanes 4 j .. 4 j + 3 hold four pixels that are
+// neighbours in a row (pixel_of), all inside the image or all outside: their twelve bytes leave as ONE 12-byte store from lane 4 j
+// instead of three one-byte stores from each of the four lanes (three store instructions of 64 scattered bytes per wave).
+template <bool PACK4_OK = false>
+DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int ix, int iy, int W, unsigned &rgb8_packed, bool pack4 = false)
 {
     rgb8_packed = 0u;
     if (!inside) return 0.0f;
@@ -1057,9 +1071,21 @@ DEV float write_pixel(const SasOutputs &o, const PixState &p, bool inside, int i
                        b2 = (unsigned)(int)floorf(fma_(v2, 255.0f, 0.5f));
         rgb8_packed = b0 | (b1 << 8) | (b2 << 16);
         if (o.rgb8) {
-            o.rgb8[3 * pix] = (uint8_t)b0;
-            o.rgb8[3 * pix + 1] = (uint8_t)b1;
-            o.rgb8[3 * pix + 2] = (uint8_t)b2;
+            if (PACK4_OK && pack4) {
+                // (the four lanes of a DPP quad are in this branch together: same row, x = 4 j .. 4 j + 3, width a multiple of four)
+                const unsigned p0 = rgb8_packed;
+                const unsigned p1 = __float_as_uint(quad_bcast<1>(__uint_as_float(p0))), p2 = __float_as_uint(quad_bcast<2>(__uint_as_float(p0))),
+                               p3 = __float_as_uint(quad_bcast<3>(__uint_as_float(p0)));
+                if ((threadIdx.x & 3) == 0) {
+                    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+                    const u32x3 v = {p0 | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+                    *reinterpret_cast<u32x3 *>(o.rgb8 + 3 * pix) = v;
+                }
+            } else {
+                o.rgb8[3 * pix] = (uint8_t)b0;
+                o.rgb8[3 * pix + 1] = (uint8_t)b1;
+                o.rgb8[3 * pix + 2] = (uint8_t)b2;
+            }
         }
     }
     return ED;
@@ -1362,17 +1388,40 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         s_hist[tid] = 0u;
         __syncthreads();
+        // Lists of up to kKeyCache keys -- most of the long ones -- are read from memory ONCE: the min / max pass parks them in the
+        // part of the staging region that the ordering scratch leaves free (15 KiB), the histogram and the first round's collect
+        // pass read them from there (two dependent global round trips per tile less).  The first compositing overwrites the copy:
+        // later rounds (the exception: the first chunk did not saturate the tile) read the segment again.
+        constexpr int kKeyCache = (kBlendLdsBytes - 6 * 1024) / 8;   // behind cnt / dbase / s_cur (6 KiB)
+        unsigned long long *const kc = reinterpret_cast<unsigned long long *>(s_raw + 6 * 1024);
+        const bool cached = n <= kKeyCache;   // (uniform)
         unsigned mn = ~0u, mx = 0u;
-        for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
-            unsigned dd[U];
+        if (cached) {
+            for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+                unsigned long long kk[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * kLazyThreads + tid;
-                dd[u] = (i < n) ? hi32(g[i]) : 0u;
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLazyThreads + tid;
+                    kk[u] = (i < n) ? g[i] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLazyThreads + tid;
+                    if (i < n) { mn = min(mn, hi32(kk[u])); mx = max(mx, hi32(kk[u])); if (SAS_IN(i, kKeyCache, 222)) kc[i] = kk[u]; }
+                }
             }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+                unsigned dd[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (i0 + u * kLazyThreads + tid < n) { mn = min(mn, dd[u]); mx = max(mx, dd[u]); }
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLazyThreads + tid;
+                    dd[u] = (i < n) ? hi32(g[i]) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (i0 + u * kLazyThreads + tid < n) { mn = min(mn, dd[u]); mx = max(mx, dd[u]); }
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
@@ -1382,16 +1431,23 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         const unsigned dmin = s_mn, span = s_mx - s_mn;
         const int sbits = span ? 32 - __clz(span) : 0;
         const int shift = sbits > 8 ? sbits - 8 : 0;   // 256 depth buckets over the tile's range
-        for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
-            unsigned dd[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * kLazyThreads + tid;
-                dd[u] = (i < n) ? hi32(g[i]) : 0u;
+        if (cached) {
+            for (int i = tid; i < n; i += kLazyThreads) {
+                const unsigned dd = hi32(kc[i]);
+                if (SAS_IN((dd - dmin) >> shift, 256, 208)) atomicAdd(&s_hist[(dd - dmin) >> shift], 1u);
             }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
+                unsigned dd[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (i0 + u * kLazyThreads + tid < n && SAS_IN((dd[u] - dmin) >> shift, 256, 208)) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLazyThreads + tid;
+                    dd[u] = (i < n) ? hi32(g[i]) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (i0 + u * kLazyThreads + tid < n && SAS_IN((dd[u] - dmin) >> shift, 256, 208)) atomicAdd(&s_hist[(dd[u] - dmin) >> shift], 1u);
+            }
         }
         __syncthreads();
         PH_LAP(2);
@@ -1468,7 +1524,17 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             }
             const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
             const unsigned long long t_c = PH_T();
-            if (!partitioned) {
+            if (!partitioned && cached && b_next == 0) {
+                // first round of a cached list: the keys are in LDS
+                for (int i = tid; i < n; i += kLazyThreads) {
+                    const unsigned long long key = kc[i];
+                    const int b = (int)((hi32(key) - dmin) >> shift);
+                    if (b >= b0 && b <= b1 && SAS_IN(b, 256, 206)) {
+                        const unsigned pos = atomicAdd(&s_cur[b], 1u);
+                        if (SAS_IN(pos, CH, 207)) ck[pos] = ((unsigned long long)(hi32(key) - base) << 32) | lo32(key);
+                    }
+                }
+            } else if (!partitioned) {
                 for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
                     unsigned long long kk[U];
 #pragma unroll
@@ -1536,7 +1602,9 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         }
     }
     unsigned packed;
-    const float ED = write_pixel(o, p, inside && writer, ix, iy, c.W, packed);
+    float ED;
+    if constexpr (QUAD) ED = write_pixel(o, p, inside && writer, ix, iy, c.W, packed);
+    else ED = write_pixel<true>(o, p, inside, ix, iy, c.W, packed, o.rgb8 && (c.W & 3) == 0 && ((size_t)o.rgb8 & 3) == 0);
     if (o.rgb8_host) {   // (uniform: a frame property; out_side is uniform over the workgroup)
         if (out_side == 16) store_rows_to_host<16>(o.rgb8_host, c.W, tx * SAS_TILE, ty * SAS_TILE, ox, oy, writer, packed, s_raw);
         else if (out_side == 8) store_rows_to_host<8>(o.rgb8_host, c.W, tx * SAS_TILE + (qd & 1) * 8, ty * SAS_TILE + (qd >> 1) * 8,
