@@ -29,8 +29,8 @@ Clock ramp.  After an idle period (the seconds of scene generation in front of t
 ~30 ms of sustained load to reach its steady clocks (tools/ramp_probe.py, profiles/r03_clock_ramp.txt: 0.38 -> 0.32 ms
 per step over the first four chunks of 20 steps).  W = 5 warm-up steps are 2 ms.  The bench therefore REPEATS the
 W + K protocol back to back -- W untimed steps, a synchronisation, exactly K timed steps, a synchronisation -- until
-a pass is within 1 % of the one before it (at most 8 passes; a K-step pass of more than 0.25 s is long enough by
-itself and is not repeated).  `value` is the MEDIAN of the passes behind the ramp (those that start once ~30 ms of load
+a pass is within 1 % of the one before it and three passes lie behind the ramp (at most 12 passes; a K-step pass of more
+than 0.25 s is long enough by itself and is not repeated).  `value` is the MEDIAN of the passes behind the ramp (those that start once ~30 ms of load
 have gone by; protocol version 3 -- version 2 reported the LAST pass, which depended on which of two alternating
 interleavings of the frames in flight the pass cap fell on); `converged` says whether the last two passes agreed within
 1 %, `pass_spread` is (max - min) / median over the same passes; every pass is listed in `passes`, the first one -- from
@@ -314,11 +314,13 @@ def main():
     # (two passes agreeing is accepted only once the passes so far cover the ~30 ms the clocks take to ramp: a chance
     # agreement of the second and third pass, 16 ms in, ended runs 5 % low)
     converged = a.single_pass or pass_times[-1] >= 0.25
-    while not a.single_pass and len(pass_times) < 8 and pass_times[-1] < 0.25:
+    MAX_PASSES, MIN_BEHIND_RAMP = 12, 3
+    while not a.single_pass and len(pass_times) < MAX_PASSES and pass_times[-1] < 0.25:
         elapsed, tile_ms, timed_frames = timed_pass()
         pass_times.append(elapsed)
-        if sum(pass_times[:-1]) >= 0.030 and abs(pass_times[-1] - pass_times[-2]) <= 0.01 * pass_times[-2]:
-            converged = True
+        behind = sum(1 for k in range(len(pass_times)) if sum(pass_times[:k]) >= 0.030)
+        converged = sum(pass_times[:-1]) >= 0.030 and abs(pass_times[-1] - pass_times[-2]) <= 0.01 * pass_times[-2]
+        if converged and behind >= MIN_BEHIND_RAMP:   # (a median wants more than one pass behind the ramp)
             break
     # the reported pass time: the median of the passes that STARTED behind the clock ramp (>= 30 ms of load in front of
     # them); a run too short to have one reports its last pass
@@ -392,7 +394,7 @@ def main():
             "effective_warmup_steps": a.warmup + (len(pass_times) - len(post_ramp)) * (a.warmup + a.steps),   # untimed + discarded timed steps in front of the first pass that counts
             "protocol": ("one W + K pass from the idle GPU" if a.single_pass else
                          "W warm-up + K timed steps repeated back to back until a pass is within 1 % of the one before and the passes in "
-                         "front of it cover the ~30 ms the GPU's clocks ramp for after idle (<= 8 passes); value = the MEDIAN of the passes "
+                         "front of it cover the ~30 ms the GPU's clocks ramp for after idle, and three passes lie behind that ramp (<= 12 passes); value = the MEDIAN of the passes "
                          "that start behind the ramp, converged = the last two agreed, cold_start = the first pass"),
             "passes": [{"value": views_all * a.steps / t, "ms_per_step": t / a.steps * 1e3} for t in pass_times],
             "cold_start": {"value": views_all * a.steps / cold_elapsed, "unit": "frames/s", "ms_per_step": cold_elapsed / a.steps * 1e3,

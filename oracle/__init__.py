@@ -95,6 +95,7 @@ def logf(x: float) -> float:
 
 
 VARIANT_TEXTBOOK_SIGMA, VARIANT_SIGMA_GUARD, VARIANT_T_PRODUCT, VARIANT_LIBM_EXP = 1, 2, 4, 8
+VARIANT_POLYNOMIAL_SIGMA = 32   # study: the contract of rounds 1-4 (sigma as a polynomial in the tile-local pixel centre); | 16: about the tile's corner (rounds 1-3)
 
 
 class variant:

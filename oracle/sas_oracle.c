@@ -40,7 +40,7 @@
 #endif
 
 #define OC_TILE 16
-#define OC_TILE_CENTRE 8.0f   /* the tile-local frame of T6's sigma polynomial has its origin at the tile's centre */
+#define OC_TILE_CENTRE 8.0f   /* the tile-local frame of T6 (u, v, x, y) has its origin at the tile's centre */
 #define OC_NEAR 0.01f
 #define OC_FAR 1e10f
 #define OC_EPS2D 0.3f
@@ -386,15 +386,17 @@ static int cmp_u64(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-/* T6, per (Gaussian, tile): sigma as a polynomial in the pixel centre (x, y) RELATIVE TO THE TILE'S CENTRE (X0, Y0)
- * (x, y in -7.5 .. 7.5: the terms that cancel are a quarter of what they are about the tile's corner, and with them
- * the rounding of the sum -- 40x fewer pixels moved by more than 1e-6 against the textbook form, tests/tools/deviation_table.py),
- *   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
- *   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2
- * (algebraically gsplat's 0.5 (A dx^2 + C dy^2) + B dx dy with dx = mx - px; the conic is positive
- * semi-definite, so gsplat's `sigma < 0` guard can only fire on rounding noise and is not part of
- * the contract). */
-typedef struct { float k0, k1, k2, hA, hC, B; } tcoef_t;
+/* T6, per (Gaussian, tile): the mean relative to the TILE'S CENTRE (X0, Y0), u = mx - X0, v = my - Y0, and the halved conic
+ * hA = A/2, hC = C/2.  Per pixel with centre (x, y) relative to the same origin (-7.5 .. 7.5):
+ *   dx = u - x, dy = v - y,   sigma = fma(dx, fma(B, dy, hA dx), (hC dy) dy)
+ * -- gsplat's 0.5 (A dx^2 + C dy^2) + B dx dy evaluated on (dx, dy) itself with two fused steps (round 5).  Its terms are small
+ * where sigma is small, so it sits at the float32 noise floor of the written form (one pixel beyond 1e-4 at config 3 against
+ * the all-textbook float32 frame, twelve beyond 1e-6: tests/tools/deviation_table.py --full).  Rounds 1-4 expanded sigma into
+ * a POLYNOMIAL in (x, y) -- k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y, five fused operations per pair instead of seven --
+ * whose terms cancel (four pixels beyond 1e-4, 119 beyond 1e-6 at config 3); it is kept as study variant 32 (16: about the
+ * tile's corner, the form of rounds 1-3).  The conic is positive semi-definite, so gsplat's `sigma < 0` guard can only fire
+ * on rounding noise and is not part of the contract. */
+typedef struct { float k0, k1, k2, hA, hC, B, u, v; } tcoef_t;
 
 static inline void tile_coefs(const proj_t *g, float X0, float Y0, tcoef_t *t)
 {
@@ -406,18 +408,19 @@ static inline void tile_coefs(const proj_t *g, float X0, float Y0, tcoef_t *t)
     t->k2 = -fmaf(C, v, bu);
     t->k0 = fmaf(hA * u, u, fmaf(hC * v, v, bu * v));
     t->hA = hA; t->hC = hC; t->B = B;
+    t->u = u; t->v = v;
 }
 
-/* T6 for one pixel; (x, y) = pixel centre relative to the tile origin */
+/* T6 for one pixel; (x, y) = pixel centre relative to the tile's centre */
 static inline void blend_pixel(const proj_t *P, const int32_t *ids, const tcoef_t *tc, int64_t n, float x, float y,
                                float out_acc[4], float *out_T)
 {
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, ad = 0.0f;
-    const float xx = x * x, yy = y * y, xy = x * y; /* exact: multiples of 0.25 below 64 */
     for (int64_t k = 0; k < n; ++k) {
         const proj_t *g = &P[ids[k]];
         const tcoef_t *t = &tc[k];
-        float sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
+        const float dx = t->u - x, dy = t->v - y;
+        float sigma = fmaf(dx, fmaf(t->B, dy, t->hA * dx), (t->hC * dy) * dy);
         float alpha = fminf(OC_MAX_ALPHA, g->opac * sas_oracle_expf(-sigma));
         if (alpha < OC_ALPHA_THRESHOLD) continue;
         float vis = alpha * T;
@@ -437,10 +440,11 @@ static inline void blend_pixel(const proj_t *P, const int32_t *ids, const tcoef_
  * The contract departs from gsplat's WRITTEN arithmetic in four places, each chosen for the GPU loop.
  * A variant mask switches any of them back to the textbook float32 form, so that the effect of each on an
  * image can be measured against the float64 twin (oracle/np_twin.py, which keeps all four textbook forms):
- *   1  sigma = 0.5 (A dx^2 + C dy^2) + B dx dy on (dx, dy) = (mx - px, my - py) instead of the tile polynomial
+ *   1  sigma = 0.5 (A dx^2 + C dy^2) + B dx dy, unfused, on (dx, dy) = (mx - px, my - py) instead of the contract's fused form on (u - x, v - y)
  *   2  gsplat's `sigma < 0 -> skip` guard restored
  *   4  T' = T (1 - alpha) instead of T - alpha T
  *   8  libm expf instead of the degree-5 polynomial
+ *  32  (study) the contract of rounds 1-4: sigma as a polynomial in the tile-local pixel centre (16 on top: about the tile's corner)
  * Mask 0 is the contract and the only thing the parity tests and the CPU baseline ever run. */
 static int g_variant = 0;
 void sas_oracle_set_variant(int mask) { g_variant = mask; }
@@ -457,8 +461,11 @@ static inline void blend_pixel_variant(int variant, const proj_t *P, const int32
         if (variant & 1) {
             float dx = g->mx - px, dy = g->my - py;
             sigma = 0.5f * (g->ca * dx * dx + g->cc * dy * dy) + g->cb * dx * dy;
-        } else {
+        } else if (variant & 32) {
             sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
+        } else {
+            float dx = t->u - x, dy = t->v - y;
+            sigma = fmaf(dx, fmaf(t->B, dy, t->hA * dx), (t->hC * dy) * dy);
         }
         if ((variant & 2) && sigma < 0.0f) continue;
         float e = (variant & 8) ? expf(-sigma) : sas_oracle_expf(-sigma);
@@ -491,9 +498,12 @@ static inline int decide_variant(int variant, const proj_t *g, const tcoef_t *t,
     if (variant & 1) {
         float dx = g->mx - px, dy = g->my - py;
         sigma = 0.5f * (g->ca * dx * dx + g->cc * dy * dy) + g->cb * dx * dy;
-    } else {
+    } else if (variant & 32) {
         const float xx = x * x, yy = y * y, xy = x * y;
         sigma = fmaf(t->B, xy, fmaf(t->hC, yy, fmaf(t->hA, xx, fmaf(t->k2, y, fmaf(t->k1, x, t->k0)))));
+    } else {
+        float dx = t->u - x, dy = t->v - y;
+        sigma = fmaf(dx, fmaf(t->B, dy, t->hA * dx), (t->hC * dy) * dy);
     }
     *o_sigma = sigma;
     *o_alpha = 0.0f;
@@ -623,7 +633,7 @@ int sas_oracle_render(const sas_oracle_scene *s, const float viewmat[16], const 
         const int32_t *tl = ids + tcount[t];
         int64_t tn = tcount[t + 1] - tcount[t];
         tcoef_t *tc = tc_all + (size_t)oc_thread_id() * (size_t)max_len;
-        /* the polynomial is taken about the tile's CENTRE (variant 16: about its corner, the form of rounds 1-3, for the study) */
+        /* the tile-local frame has its origin at the tile's CENTRE (variant 16, with 32: the polynomial about the corner, rounds 1-3, for the study) */
         const float cen = (g_variant & 16) ? 0.0f : OC_TILE_CENTRE;
         for (int64_t k = 0; k < tn; ++k) tile_coefs(&P[tl[k]], (float)(tx * OC_TILE) + cen, (float)(ty * OC_TILE) + cen, &tc[k]);
         for (int yy = 0; yy < OC_TILE; ++yy) {

@@ -477,19 +477,18 @@ struct PixState {
     float T, r, g, b, d;
     float x;
 };
-// loop-invariant powers of the pixel's tile-local centre (exact: multiples of 0.25 below 64)
+// the pixel's tile-local row (its column is PixState::x, which doubles as the parking flag)
 struct PixConst {
-    float y, xx, yy, xy;
+    float y;
 };
 DEV bool pix_dead(const PixState &p) { return p.x != p.x; }
-// Contract T6: the sigma polynomial's frame has its origin at the CENTRE of the 16-pixel tile (x, y in -7.5 .. 7.5: the
-// cancelling terms, and with them the rounding of the sum, are a quarter of what they are about the tile's corner)
+// Contract T6: the tile-local frame (u, v, x, y) has its origin at the CENTRE of the 16-pixel tile (x, y in -7.5 .. 7.5)
 constexpr float kTileCentre = 8.0f;
 DEV PixState pix_init(bool inside, int ox) { return PixState{1.0f, 0.f, 0.f, 0.f, 0.f, inside ? ((float)ox + 0.5f) - kTileCentre : __builtin_nanf("")}; }
 DEV PixConst pix_const(int ox, int oy)
 {
-    const float x = ((float)ox + 0.5f) - kTileCentre, y = ((float)oy + 0.5f) - kTileCentre;
-    return PixConst{y, x * x, y * y, x * y};
+    (void)ox;
+    return PixConst{((float)oy + 0.5f) - kTileCentre};
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
@@ -685,20 +684,15 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             DBG_ADD(15, c);
         }
 #endif
-        // Contract T6: sigma as a polynomial in the tile-local pixel centre (x, y),
-        //   sigma = k0 + k1 x + k2 y + hA x^2 + hC y^2 + B x y,   u = mx - X0, v = my - Y0,
-        //   k1 = -(A u + B v), k2 = -(C v + B u), k0 = hA u^2 + hC v^2 + B u v, hA = A/2, hC = C/2,
-        // five FMAs per pixel in the loop instead of nine operations on (dx, dy).
+        // Contract T6 (round 5): sigma on (dx, dy) = (u - x, v - y) in the frame of the tile's centre, u = mx - X0, v = my - Y0:
+        //   sigma = fma(dx, fma(B, dy, hA dx), (hC dy) dy),   hA = A/2, hC = C/2
+        // -- seven operations per pixel-splat pair.  (Rounds 1-4 expanded it into a polynomial in (x, y): five, but its terms
+        // cancel; the (dx, dy) form costs the tile kernel 3 % and sits at the float32 noise floor of gsplat's written form.)
         {
             const float u = ra.x - X0, v = ra.y - Y0;
             const float A = ra.z, B = ra.w, C = rb.x;
-            const float hA = 0.5f * A, hC = 0.5f * C;
-            const float bu = B * u;
-            const float k1 = -fma_(A, u, B * v);
-            const float k2 = -fma_(C, v, bu);
-            const float k0 = fma_(hA * u, u, fma_(hC * v, v, bu * v));
-            L.q0[tid] = make_float4(k0, k1, k2, hA);
-            L.q1[tid] = make_float4(hC, B, rb.z, rb.y);          // .z threshold, .w opacity
+            L.q0[tid] = make_float4(u, v, 0.0f, 0.5f * A);
+            L.q1[tid] = make_float4(0.5f * C, B, rb.z, rb.y);    // .z threshold, .w opacity
             L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);     // colour, depth
             L.mask[tid] = ment;
         }
@@ -776,8 +770,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             };
             // returns true when every pixel of the wave has terminated
             auto composite_trip = [&](const Trip &t) -> bool {
-                const float sg0 = fma_(t.H0.y, pc.xy, fma_(t.H0.x, pc.yy, fma_(t.K0.w, pc.xx, fma_(t.K0.z, pc.y, fma_(t.K0.y, p.x, t.K0.x)))));
-                const float sg1 = fma_(t.H1.y, pc.xy, fma_(t.H1.x, pc.yy, fma_(t.K1.w, pc.xx, fma_(t.K1.z, pc.y, fma_(t.K1.y, p.x, t.K1.x)))));
+                const float dx0 = t.K0.x - p.x, dy0 = t.K0.y - pc.y, dx1 = t.K1.x - p.x, dy1 = t.K1.y - pc.y;
+                const float sg0 = fma_(dx0, fma_(t.H0.y, dy0, t.K0.w * dx0), (t.H0.x * dy0) * dy0);
+                const float sg1 = fma_(dx1, fma_(t.H1.y, dy1, t.K1.w * dx1), (t.H1.x * dy1) * dy1);
                 // Every decision below is a per-lane select on a value, not a wave mask combined on the
                 // scalar unit (which the CU's four SIMDs share: a scalar instruction costs as much issue time
                 // as a vector one).  A lane the splat does not reach has a large sigma: the contract's clamp
@@ -922,16 +917,11 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
         PH_ADD(4, t_b1 - t_b0);
         unsigned ment = 0u;
         if (have) ment = block_mask4(tx, ty, qd, ra.x, ra.y, ra.z, ra.w, rb.x, rb.z);
-        {
+        {   // (contract T6: see blend_range)
             const float u = ra.x - X0, v = ra.y - Y0;
             const float A = ra.z, B = ra.w, C = rb.x;
-            const float hA = 0.5f * A, hC = 0.5f * C;
-            const float bu = B * u;
-            const float k1 = -fma_(A, u, B * v);
-            const float k2 = -fma_(C, v, bu);
-            const float k0 = fma_(hA * u, u, fma_(hC * v, v, bu * v));
-            L.q0[tid] = make_float4(k0, k1, k2, hA);
-            L.q1[tid] = make_float4(hC, B, rb.z, rb.y);
+            L.q0[tid] = make_float4(u, v, 0.0f, 0.5f * A);
+            L.q1[tid] = make_float4(0.5f * C, B, rb.z, rb.y);
             L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);
             L.mask[tid] = ment;
         }
@@ -981,7 +971,8 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                     const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
                     k += 4;
                     off = wq[k + e];   // next trip's entry, one trip ahead
-                    const float sg = fma_(H.y, pc.xy, fma_(H.x, pc.yy, fma_(K.w, pc.xx, fma_(K.z, pc.y, fma_(K.y, p.x, K.x)))));
+                    const float dxq = K.x - p.x, dyq = K.y - pc.y;
+                    const float sg = fma_(dxq, fma_(H.y, dyq, K.w * dxq), (H.x * dyq) * dyq);
                     const float E = FAST_EXP ? __expf(fmaxf(-sg, -86.0f)) : c_expf_neg(fmaxf(-sg, -86.0f), sE5);
                     const float al = fminf(kMaxAlpha, H.w * E);
                     // A skipped splat weighs 0: decided HERE, once per lane for its own entry, so that the chain below is one

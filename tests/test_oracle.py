@@ -177,7 +177,7 @@ def test_contract_deviations_from_the_textbook_formulas_stay_far_below_the_parit
     for name in CASES:
         row = dt.measure(name)
         assert row["no sigma<0 guard"] == 0.0, row
-        for label in ("polynomial sigma", "T - alpha T", "polynomial exp", "contract vs f64 twin", "textbook f32 vs f64 twin"):
+        for label in ("fused (dx, dy) sigma", "T - alpha T", "polynomial exp", "contract vs f64 twin", "textbook f32 vs f64 twin"):
             assert row[label] <= 5e-5, (label, row)
 
 
@@ -185,7 +185,7 @@ def test_contract_deviations_from_the_textbook_formulas_stay_far_below_the_parit
 ALL_TEXTBOOK = oracle.VARIANT_TEXTBOOK_SIGMA | oracle.VARIANT_SIGMA_GUARD | oracle.VARIANT_T_PRODUCT | oracle.VARIANT_LIBM_EXP
 
 
-@pytest.mark.parametrize("cfg", [2, 3])
+@pytest.mark.parametrize("cfg", [2, 3, 5])
 def test_contract_vs_textbook_at_full_size_differs_only_through_threshold_flips(cfg):
     """DESIGN.md 3, the claim with numbers under it.  Two float32 evaluations of gsplat's compositing (the contract's
     operation order and the textbook's) cannot agree to 1e-4 on EVERY pixel of a 2-Mpixel frame of 1 M Gaussians:
@@ -194,7 +194,10 @@ def test_contract_vs_textbook_at_full_size_differs_only_through_threshold_flips(
       * at most 5 pixels per Mpixel (and never more than 2 + that) differ by more than 1e-4;
       * EVERY such pixel is a flip: the oracle's tracer finds the list entry where the two evaluations decide
         differently, and both sides' alpha (or next T) lie within 1e-4 relative of each other, the threshold between them;
-      * away from flips the frames agree to 2e-5 (continuous rounding only)."""
+      * away from flips the frames agree to 2e-5 (continuous rounding only).
+    Config 5 (view 0: 5 M Gaussians, colours up to 30) is held to the same bound since round 5.  (Round 5's contract evaluates
+    sigma on (dx, dy) itself instead of the tile polynomial of rounds 1-4: 0 / 1 / 0 pixels beyond 1e-4 at configs 2 / 3 / 5
+    where the polynomial had 0 / 4 / 0 -- tests/tools/deviation_table.py --full.)"""
     from sim_a_splat_amd.synthetic import NERFSTUDIO_EVAL_BACKGROUND as BG, config_scene_and_cameras
     sc, cams = config_scene_and_cameras(cfg)
     cam = cams[0]

@@ -21,9 +21,10 @@ import oracle  # noqa: E402
 from conftest import TWIN_CASES, load_twin_fixture, twin_scene_kwargs  # noqa: E402
 
 ALL = oracle.VARIANT_TEXTBOOK_SIGMA | oracle.VARIANT_SIGMA_GUARD | oracle.VARIANT_T_PRODUCT | oracle.VARIANT_LIBM_EXP
-FORMS = (("polynomial sigma", oracle.VARIANT_TEXTBOOK_SIGMA), ("no sigma<0 guard", oracle.VARIANT_SIGMA_GUARD),
+FORMS = (("fused (dx, dy) sigma", oracle.VARIANT_TEXTBOOK_SIGMA), ("no sigma<0 guard", oracle.VARIANT_SIGMA_GUARD),
          ("T - alpha T", oracle.VARIANT_T_PRODUCT), ("polynomial exp", oracle.VARIANT_LIBM_EXP))
-CORNER = 16   # study-only switch of the oracle: the sigma polynomial about the tile's corner (the contract of rounds 1-3)
+POLY = oracle.VARIANT_POLYNOMIAL_SIGMA   # study-only switch of the oracle: sigma as a polynomial in the tile-local pixel centre (the contract of rounds 1-4)
+CORNER = 16   # ... on top of POLY: the polynomial about the tile's corner (the contract of rounds 1-3)
 
 
 def render(g, mask):
@@ -67,9 +68,12 @@ def full_size(cfg, view=0):
     print("| form | max d rgb | pixels > 1e-4 | > 1e-5 | > 1e-6 |\n|---|---|---|---|---|")
     for label, bit in FORMS:
         print(count_row(label + " alone", r(ALL & ~bit), text))
-    print(count_row("polynomial sigma about the tile's CORNER alone (rounds 1-3)", r((ALL & ~oracle.VARIANT_TEXTBOOK_SIGMA) | CORNER), text))
     print(count_row("**contract**", r(0), text))
-    print(count_row("contract of rounds 1-3 (corner)", r(CORNER), text))
+    NS = ALL & ~oracle.VARIANT_TEXTBOOK_SIGMA
+    print(count_row("polynomial sigma about the tile's centre alone (rounds 1-4's form)", r(NS | POLY), text))
+    print(count_row("polynomial sigma about the tile's CORNER alone (rounds 1-3's form)", r(NS | POLY | CORNER), text))
+    print(count_row("contract of round 4 (polynomial about the centre)", r(POLY), text))
+    print(count_row("contract of rounds 1-3 (polynomial about the corner)", r(POLY | CORNER), text))
 
 
 if __name__ == "__main__":
