@@ -4,6 +4,9 @@
 #include <stdint.h>
 
 #define SAS_TILE 16
+#ifndef SAS_TILE_GROUP
+#define SAS_TILE_GROUP 4   // tiles per unit of the tile order a single-pass projection's tail writes (A/B builds: 1)
+#endif
 // record / colour strides in float4: a 32-byte record and a colour array of its own.  (Measured against the colour inside a
 // 48-byte record as rounds 1-4 had it, the two roles of the projection each writing part of every line: projection +5 us, tile
 // kernel +1.5 us, pair bench -5 %: profiles/r05_ab_record_layout.txt.)

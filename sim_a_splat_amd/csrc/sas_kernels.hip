@@ -124,6 +124,73 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
     for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(r[c] + 0.5f, 0.0f);
 }
 
+// Degree 3 in two halves, for the projection's colour role: the first six coefficient planes (coefficients 0 .. 7 of the three
+// channels) are consumed before the last six are loaded, so a lane holds 24 coefficients at a time instead of 48 -- the pair
+// kernel (two evaluations per lane) then fits the 64 registers of eight waves per SIMD.  A channel's sum is the same chain in
+// coefficient order as sh_to_color's: identical bits.
+struct ShHalf {
+    float x, y, z, z2, fC1, fS1;
+    float r[3];
+};
+DEV void sh3_first(const float *a /* floats 0 .. 23 */, float dx, float dy, float dz, ShHalf &S)
+{
+    float inorm = 1.0f / sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+    S.x = dx * inorm; S.y = dy * inorm; S.z = dz * inorm;
+    const float x = S.x, y = S.y, z = S.z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = 0.2820947917738781f * a[0 * 3 + c];
+        float t = fma_(-x, a[3 * 3 + c], fma_(z, a[2 * 3 + c], (-y) * a[1 * 3 + c]));
+        S.r[c] = fma_(0.48860251190292f, t, r);
+    }
+    S.z2 = z * z;
+    S.fC1 = fma_(x, x, -(y * y));
+    S.fS1 = 2.0f * x * y;
+    const float fTmp0B = -1.092548430592079f * z;
+    const float pSH6 = fma_(0.9461746957575601f, S.z2, -0.3153915652525201f);
+    const float pSH7 = fTmp0B * x;
+    const float pSH5 = fTmp0B * y;
+    const float pSH4 = 0.5462742152960395f * S.fS1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = S.r[c];
+        r = fma_(pSH4, a[4 * 3 + c], r);
+        r = fma_(pSH5, a[5 * 3 + c], r);
+        r = fma_(pSH6, a[6 * 3 + c], r);
+        r = fma_(pSH7, a[7 * 3 + c], r);
+        S.r[c] = r;
+    }
+}
+DEV void sh3_second(const float *b /* floats 24 .. 47: coefficient k of channel c at b[3 (k - 8) + c] */, const ShHalf &S, float *rgb)
+{
+    const float x = S.x, y = S.y, z = S.z, z2 = S.z2, fC1 = S.fC1, fS1 = S.fS1;
+    const float pSH8 = 0.5462742152960395f * fC1;
+    const float fTmp0C = fma_(-2.285228997322329f, z2, 0.4570457994644658f);
+    const float fTmp1B = 1.445305721320277f * z;
+    const float fC2 = fma_(x, fC1, -(y * fS1));
+    const float fS2 = fma_(x, fS1, y * fC1);
+    const float pSH12 = z * fma_(1.865881662950577f, z2, -1.119528997770346f);
+    const float pSH13 = fTmp0C * x;
+    const float pSH11 = fTmp0C * y;
+    const float pSH14 = fTmp1B * fC1;
+    const float pSH10 = fTmp1B * fS1;
+    const float pSH15 = -0.5900435899266435f * fC2;
+    const float pSH9 = -0.5900435899266435f * fS2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = S.r[c];
+        r = fma_(pSH8, b[0 * 3 + c], r);
+        r = fma_(pSH9, b[1 * 3 + c], r);
+        r = fma_(pSH10, b[2 * 3 + c], r);
+        r = fma_(pSH11, b[3 * 3 + c], r);
+        r = fma_(pSH12, b[4 * 3 + c], r);
+        r = fma_(pSH13, b[5 * 3 + c], r);
+        r = fma_(pSH14, b[6 * 3 + c], r);
+        r = fma_(pSH15, b[7 * 3 + c], r);
+        rgb[c] = fmaxf(r + 0.5f, 0.0f);
+    }
+}
+
 // Visit every tile of a rectangle.  Small rectangles are walked by their own lane; a lane with a
 // large rectangle hands it to the whole wave (64 lanes stride over its tiles) so that one
 // screen-filling Gaussian does not serialise a wave.  v0/v1 are the owning lane's payload; they
@@ -577,7 +644,11 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
     int *s_bins = lds + 16;      // [16 classes (descending)][32 copies]
     int *s_off = s_bins + 512, *s_rank = s_off + 512, *s_ctot = s_rank + 512;
     unsigned char *s_clsb = reinterpret_cast<unsigned char *>(lds + kTailScratch);   // class of group w = tiles 4 w .. 4 w + 3
+#if SAS_TILE_GROUP == 1
+    constexpr int kClsGroups = 2 * kHistBins - kTailScratch;   // (a word of four class bytes per group)
+#else
     constexpr int kClsGroups = 4 * (2 * kHistBins - kTailScratch);
+#endif
     const int words = (tiles + 3) >> 2;       // groups of four tiles = 16-byte words of counts
     const bool in_lds = words <= kClsGroups;   // (uniform)
     const int4 *cnt4 = reinterpret_cast<const int4 *>(f.tile_count);   // (zero-padded past its end: sas_count_stride)
@@ -616,9 +687,22 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
             total += (c[j].x + c[j].y) + (c[j].z + c[j].w);
             const int gmax = max(max(c[j].x, c[j].y), max(c[j].z, c[j].w));
             maxlen = max(maxlen, gmax);
+#if SAS_TILE_GROUP == 1   // A/B build: the order's unit is a tile (four class bytes per word, four times the atomics and order stores)
+            const int cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+            unsigned packed = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (4 * w + q >= tiles) break;
+                const int cl = 15 - len_class(cc[q]);
+                packed |= (unsigned)cl << (8 * q);
+                atomicAdd(&s_bins[cl * 32 + (lane & 31)], 1);
+            }
+            if (in_lds) reinterpret_cast<unsigned *>(s_clsb)[w] = packed;
+#else
             const int cl = 15 - len_class(gmax);
             atomicAdd(&s_bins[cl * 32 + (lane & 31)], 1);
             if (in_lds) s_clsb[w] = (unsigned char)cl;
+#endif
         }
     }
 #pragma unroll
@@ -665,6 +749,23 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
     //      b renders tile 4 tile_order[b / 4] + b % 4)
 #pragma unroll 4
     for (int w = tid; w < words; w += 256) {
+#if SAS_TILE_GROUP == 1
+        unsigned packed;
+        if (in_lds) {
+            packed = reinterpret_cast<const unsigned *>(s_clsb)[w];
+        } else {
+            const int4 c = cnt4[w];
+            packed = (unsigned)(15 - len_class(c.x)) | ((unsigned)(15 - len_class(c.y)) << 8) | ((unsigned)(15 - len_class(c.z)) << 16) |
+                     ((unsigned)(15 - len_class(c.w)) << 24);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * w + q >= tiles) break;
+            const int b = (int)((packed >> (8 * q)) & 255u) * 32 + (lane & 31);
+            const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
+            if (SAS_IN(pos, tiles, 105)) f.tile_order[pos] = 4 * w + q;
+        }
+#else
         int cl;
         if (in_lds) {
             cl = (int)s_clsb[w];
@@ -675,6 +776,7 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
         const int b = cl * 32 + (lane & 31);
         const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
         if (SAS_IN(pos, words, 105)) f.tile_order[pos] = w;
+#endif
     }
     if (tid == 0) {
         const int carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
@@ -1135,27 +1237,55 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
         any_ok = any_ok || ok[v];
     }
     if (!any_ok) return;
-    constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
-    constexpr int PL = (KF + 3) / 4;
-    float sh[PL * 4];
+    if constexpr (DEG == 3) {
+        // two halves of six planes each (sh3_first / sh3_second): 24 coefficients in registers at a time
+        float a[24];
 #pragma unroll
-    for (int p = 0; p < PL; ++p) {
-        const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
-        sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
-    }
-    // (one view after the other: the scheduling barrier keeps the compiler from interleaving the two evaluations, which costs registers)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        if (v > 0) __builtin_amdgcn_sched_barrier(0);
-        if (!ok[v]) continue;
-        const SasCam &c = vs.cam[v];
-        float rgb[3];
-        if constexpr (DEG >= 0) {
-            sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
-        } else {
-            rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
+        for (int p = 0; p < 6; ++p) {
+            const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
+            a[4 * p] = q.x; a[4 * p + 1] = q.y; a[4 * p + 2] = q.z; a[4 * p + 3] = q.w;
         }
-        if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+        ShHalf S[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const SasCam &c = vs.cam[v];
+            sh3_first(a, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], S[v]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the second half's loads stay behind the first half's arithmetic: that is the point)
+        float b[24];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const float4 q = scene_load<NV>(s.col + (int64_t)(p + 6) * s.n_pad + i);
+            b[4 * p] = q.x; b[4 * p + 1] = q.y; b[4 * p + 2] = q.z; b[4 * p + 3] = q.w;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float rgb[3];
+            sh3_second(b, S[v], rgb);
+            if (ok[v] && !(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+        }
+    } else {
+        constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
+        constexpr int PL = (KF + 3) / 4;
+        float sh[PL * 4];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            const float4 q = scene_load<NV>(s.col + (int64_t)p * s.n_pad + i);
+            sh[4 * p] = q.x; sh[4 * p + 1] = q.y; sh[4 * p + 2] = q.z; sh[4 * p + 3] = q.w;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v > 0) __builtin_amdgcn_sched_barrier(0);   // (one view after the other: interleaving the evaluations costs registers)
+            if (!ok[v]) continue;
+            const SasCam &c = vs.cam[v];
+            float rgb[3];
+            if constexpr (DEG >= 0) {
+                sh_to_color<DEG>(sh, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], rgb);
+            } else {
+                rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
+            }
+            if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+        }
     }
 #ifdef SAS_TUNE_PTIME
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (instrumented build: the stamp is taken when the stores have been acknowledged)

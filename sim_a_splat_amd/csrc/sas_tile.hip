@@ -1243,8 +1243,13 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     // (the grid is the tile count rounded up to whole groups: the last group may be ragged; all of this is uniform)
     int tile;
     if (f.seg > 0) {
+#if SAS_TILE_GROUP == 1
+        if (wg >= (unsigned)f.n_tiles) return;
+        tile = f.tile_order[wg];
+#else
         tile = 4 * f.tile_order[wg >> 2] + (int)(wg & 3u);
         if (tile >= f.n_tiles) return;
+#endif
     } else {
         if (wg >= (unsigned)f.n_tiles) return;
         tile = f.tile_order[wg];
