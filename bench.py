@@ -118,17 +118,22 @@ def cpu_baseline(scene, cam, budget_s=20.0):
                       f"OpenMP on {threads} threads of {os.cpu_count()} host CPUs"}
 
 
-def workload(cfg, rank, world, views_per_step, n_gaussians):
-    """(scene, cameras of THIS rank, want, per-step group poses or None, description, scaling, all-rank views per step)."""
+def workload(cfg, rank, world, views_per_step, n_gaussians, with_scene=True):
+    """(scene, cameras of THIS rank, want, per-step group poses or None, description, scaling, all-rank views per step).
+    ``with_scene=False`` (ranks that receive the scene from rank 0: distributed.broadcast_scene): scene is None."""
     if cfg == 3:
-        scene = make_scene(n_gaussians, seed=3, log_scale_mean=float(np.log(0.006)))
+        scene = make_scene(n_gaussians, seed=3, log_scale_mean=float(np.log(0.006))) if with_scene else None
         cams = [ring_camera(1920, 1080, 1000.0, yaw_deg=45.0 * rank + 180.0 * v) for v in range(views_per_step)]
         desc = (f"BASELINE config 3: {n_gaussians / 1e6:g}M synthetic Gaussians (seed 3, SH degree 3), 1920x1080, fx=fy=1000, "
                 f"{views_per_step} independent view(s) per GPU per step"
                 + (" (a view pair shares one projection pass)" if views_per_step == 2 else "") + ", float32 RGB + uint8 RGB out per view "
                 "(no accumulation / depth in `value`: the pipelined figure with every output GaussianSplat.render returns is `door_a_async`)")
         return scene, cams, ("rgb", "rgb8"), None, desc, "weak", world * views_per_step
-    scene, all_cams = config_scene_and_cameras(cfg)
+    if with_scene:
+        scene, all_cams = config_scene_and_cameras(cfg)
+    else:
+        from sim_a_splat_amd.synthetic import config_cameras
+        scene, all_cams = None, config_cameras(cfg)
     mine = sdist.shard_views(len(all_cams), rank, world)
     cams = [all_cams[v] for v in mine]
     if cfg == 4:
@@ -241,7 +246,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    scene, cams, want, step_poses, desc, scaling, views_all = workload(a.config, rank, world, a.views_per_step, a.gaussians)
+    # the scene is made once, on rank 0, and broadcast (RCCL: ncclBroadcast of device tensors over xGMI; gloo in the rehearsal)
+    scene, cams, want, step_poses, desc, scaling, views_all = workload(a.config, rank, world, a.views_per_step, a.gaussians, with_scene=rank == 0)
+    scene = sdist.broadcast_scene(scene, rank, world, device=dev)
     V = len(cams)                                  # views this rank renders per step (0 for a rank beyond the view count)
     cam = cams[0] if cams else ring_camera(1920, 1080, 1000.0)
     W, H = (cam.width, cam.height)
@@ -421,6 +428,16 @@ def main():
                          "step_algorithmic_bytes": step_bytes, "frame_algorithmic_GBps": step_gbps,
                          "frame_frac": step_gbps / HBM_PEAK_GBPS},
         }
+        # The projection (k_project, round 5: a geometry role and a colour role in one launch) against the same roof, isolated, from
+        # the same ten blocking frames: SURVEY.md 8d's terms N*236 (scene) + N_vis*44 (record + colour) + keys*8 (what was binned)
+        if stage and cams:
+            nk = int(round(np.mean([pv.get("n_keys", pv["n_isect"]) for pv in per_view])))
+            pb = scene_pass_bytes(scene.n) + st["n_visible"] * 44 + nk * 8
+            pms = float(np.mean(stage["project"]))
+            line["roofline_projection"] = {"bound": "hbm", "kernel": "k_project", "achieved": pb / (pms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                           "frac": pb / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": pms, "algorithmic_bytes": pb, "n_keys": nk,
+                                           "traffic": pmc_traffic("k_project") if a.config == 3 else None,
+                                           "what": "one view's projection alone on the GPU (tail included): N*236 + N_vis*44 + keys*8 bytes / its mean duration"}
         # The tile kernel moves 211 MB in ~135 us: HBM is not what bounds it.  Its roof is instruction issue;
         # instruction counts per launch come from the committed rocprofv3 --pmc summary of this command.
         insts = committed("tile_insts.json") if a.config == 3 else None

@@ -39,6 +39,49 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_views, world))
 
 
+def broadcast_scene(scene, rank: int, world: int, src: int = 0, device: Optional[torch.device] = None,
+                    fields: Sequence[str] = ("means", "quats", "scales", "opacities", "sh", "group_id")):
+    """The scene, replicated: rank ``src`` passes an object with the array attributes ``fields`` (NumPy arrays or tensors; a
+    ``None`` attribute is skipped) plus ``sh_degree``; every other rank passes ``None`` and RECEIVES it -- one
+    ``dist.broadcast`` per array over the backend (RCCL: device tensors over xGMI, ``ncclBroadcast``; gloo: host tensors),
+    instead of every rank reading or generating its own copy (SURVEY.md 8e: "Scene broadcast at load: ncclBroadcast once";
+    1 M Gaussians = 236 MB).  Returns a ``types.SimpleNamespace`` with the same attributes as tensors on ``device`` (RCCL) or
+    on the host (gloo) -- ``Rasterizer.upload`` takes either -- and ``n``, ``sh_degree``.  A world of one returns ``scene``."""
+    import types
+    import numpy as np
+    if world <= 1 or not dist.is_initialized():
+        return scene
+    on_device = dist.get_backend() == "nccl"
+    dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_device else torch.device("cpu")
+    meta = [None]
+    if rank == src:
+        if scene is None:
+            raise ValueError("the source rank must pass the scene")
+        present = {}
+        for k in fields:
+            a = getattr(scene, k, None)
+            if a is not None:
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+                present[k] = (tuple(t.shape), str(t.dtype).replace("torch.", ""))
+        meta = [{"fields": present, "sh_degree": int(getattr(scene, "sh_degree", 3))}]
+    dist.broadcast_object_list(meta, src=src)
+    out = types.SimpleNamespace(sh_degree=meta[0]["sh_degree"])
+    for k in fields:
+        if k not in meta[0]["fields"]:
+            setattr(out, k, None)
+            continue
+        shape, dt = meta[0]["fields"][k]
+        if rank == src:
+            a = getattr(scene, k)
+            t = (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(dev).contiguous()
+        else:
+            t = torch.empty(shape, dtype=getattr(torch, dt), device=dev)
+        dist.broadcast(t, src=src)
+        setattr(out, k, t)
+    out.n = int(out.means.shape[0])
+    return out
+
+
 class FrameGather:
     """Gather equally-shaped frames to rank 0 with one collective per step.
 

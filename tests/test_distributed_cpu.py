@@ -55,6 +55,40 @@ def test_shard_and_gather_two_ranks(n_views):
     assert last == [20, 21]                       # last async gather: step 2 from ranks 0 and 1
 
 
+def _scene_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sdist.init_from_env(backend="gloo")
+    from sim_a_splat_amd.synthetic import make_scene
+    mine = make_scene(300, seed=9, n_groups=3) if rank == 0 else None       # only the source rank has (loads, generates) the scene
+    got = sdist.broadcast_scene(mine, rank, world)
+    ref = make_scene(300, seed=9, n_groups=3)
+    ok = got.n == 300 and got.sh_degree == 3 and all(
+        isinstance(getattr(got, k), torch.Tensor) and np.array_equal(getattr(got, k).numpy(), getattr(ref, k))
+        for k in ("means", "quats", "scales", "opacities", "sh", "group_id"))
+    plain = sdist.broadcast_scene(make_scene(10, seed=1) if rank == 0 else None, rank, world)   # no group ids: the field stays None
+    ok = ok and plain.group_id is None and plain.n == 10
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_broadcast_from_rank0_two_ranks():
+    """the scene is replicated with ONE broadcast at load (ncclBroadcast on a multi-GPU node; gloo here): rank 0
+    holds the arrays, every other rank receives them bit for bit (and None for a field the scene does not have)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+    assert sdist.broadcast_scene("anything", 0, 1) == "anything"          # a world of one keeps what it has
+
+
 def test_shard_views_partition():
     for n in (1, 4, 8, 9):
         for w in (1, 2, 4, 8):

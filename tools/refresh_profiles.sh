@@ -26,6 +26,9 @@ if [ "${1:-}" = "--install" ]; then
   [ -f $src/api_trace.txt ] && cp $src/api_trace.txt profiles/${tag}_gym_step_api_trace.txt
   [ -f $src/issue_cost.txt ] && cp $src/issue_cost.txt profiles/${tag}_issue_cost_microbench.txt
   [ -f $src/slot_time.txt ] && cp $src/slot_time.txt profiles/${tag}_tile_slot_time_partition.txt
+  [ -f $src/proj_laps.txt ] && cp $src/proj_laps.txt profiles/${tag}_projection_workgroup_laps.txt
+  [ -f $src/project_sq_counters.txt ] && cp $src/project_sq_counters.txt profiles/${tag}_project_sq_counters.txt
+  python tools/kernel_resources.py > profiles/${tag}_kernel_resources.txt 2>&1
   [ -f $src/bounds_quad_tests.log ] && cp $src/bounds_quad_tests.log profiles/${tag}_bounds_build_quad_forced_gpu_tests.log
   [ -f $src/gpu_tests.log ] && cp $src/gpu_tests.log profiles/${tag}_gpu_tests.log
   [ -f $src/bounds_tests.log ] && cp $src/bounds_tests.log profiles/${tag}_bounds_build_gpu_tests.log
@@ -37,6 +40,9 @@ fi
 tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof_$tag
+# PART=a: benches and profiles; PART=b: counters, probes and the GPU suites (two gpurun calls: one call's limit is 20 minutes)
+part=${PART:-ab}
+if [ "$part" != "b" ]; then
 rm -rf $out; mkdir -p $out
 # the driver's own command, three times, then a long run
 for i in 1 2 3; do
@@ -51,6 +57,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3 tools/stage_probe.py --cfg 3 --frames 5 > $out/pmc_write.log 2>&1 || exit 1
 # instruction counts of the tile kernel under the bench command itself (both views of a step)
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-include-regex "k_tile_lazy" -d $out/pmc_insts_bench -o p --output-format csv -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $out/pmc_insts_bench.log 2>&1 || exit 1
+fi
+if [ "$part" = "a" ]; then tail -c 400 $out/bench.json; exit 0; fi
+mkdir -p $out
 # SQ counter groups of the tile kernel on isolated frames
 bash tools/pmc_tile.sh > $out/tile_sq_counters.txt 2>&1
 SAS_LIB_PATH=variants/lib_stats.so python3 tools/blend_stats.py 3 > $out/blend_stats.txt 2>&1
@@ -68,6 +77,9 @@ done
 /tmp/issue_probe > $out/issue_cost.txt 2>&1
 # where a tile workgroup's time goes (exclusive laps of thread 0: the -DSAS_TUNE_WGTIME build under variants/)
 SAS_LIB_PATH=variants/lib_wgtime.so timeout -k 10 300 python3 tools/wg_time.py 3 > $out/slot_time.txt 2>&1
+# ... and a projection workgroup's (geometry role: exclusive laps; both roles: when they run inside the launch; -DSAS_TUNE_PTIME build)
+SAS_LIB_PATH=variants/lib_ptime.so timeout -k 10 300 python3 tools/proj_time.py 3 > $out/proj_laps.txt 2>&1
+bash tools/pmc_tile.sh k_project > $out/project_sq_counters.txt 2>&1
 # the GPU suite: product library, bounds-checked build, bounds-checked build with the quad layout forced
 timeout -k 10 600 python3 -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1
 SAS_LIB_PATH=variants/lib_bounds.so timeout -k 10 900 python3 -m pytest tests -m gpu -q > $out/bounds_tests.log 2>&1
