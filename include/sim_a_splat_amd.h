@@ -195,7 +195,7 @@ int sas_render_batch(sas_ctx *ctx, int n_views, const float *viewmats, const flo
  * way the call returns with the pixels in place and no second round trip (device-to-host copy issued by the
  * caller after the frame) is needed.  Blocking only (SAS_ASYNC is rejected).  Nothing of the caller's on the device is
  * read or written, so the frames are NOT ordered against work pending on `stream` (two event records and two
- * stream waits per step that a 120-microsecond Gym step notices: DESIGN.md 5.34).
+ * stream waits per step that a 120-microsecond Gym step notices: docs/EXPERIMENTS.md 5.34).
  */
 int sas_render_batch_host(sas_ctx *ctx, int n_views, const float *viewmats, const float *Ks, int width, int height,
                           const float *background, unsigned flags, uint8_t *rgb8_host, void *stream);

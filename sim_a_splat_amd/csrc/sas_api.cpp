@@ -324,7 +324,7 @@ enum { ROLE_SINGLE = 0, ROLE_LEADER = 1, ROLE_FOLLOWER = 2 };
 // quad layout for views of `launch_tiles` tiles each?  By the view's own size: counting the frames in
 // flight as well measured worse -- 32 Gym cameras per step in launch groups of two run 30 % faster in the quad
 // layout than in the ordinary one even with four groups in flight (tools/vec_env_probe.py); what loses is a
-// launch that fills the chip by itself (1 200 tiles of 640x480: DESIGN.md 5.21).
+// launch that fills the chip by itself (1 200 tiles of 640x480: docs/EXPERIMENTS.md 5.21).
 bool use_quad(const sas_ctx *c, int launch_tiles, unsigned flags, bool solo)
 {
     if ((flags & SAS_FULL_SORT) || !sas_tiles_lazy_quad_ok((flags & SAS_FAST_EXP) != 0)) return false;
@@ -1188,6 +1188,10 @@ static int render_views(sas_ctx *c, const ViewCall *views, int n, int width, int
         if (rc) return rc;
     }
     c->stream = st;
+    // nothing in flight: the ring restarts at slot 0, so that a sequence of frames always meets the slots in the same order
+    // (SAS_RING_RESTART=0: the ring goes on where it stood -- bench passes of 25 steps then start on alternating slot pairs)
+    static const bool ring_restart = [] { const char *e = getenv("SAS_RING_RESTART"); return !e || atoi(e) != 0; }();
+    if (ring_restart && c->inflight == 0) c->head = 0;
     Slot *sl[SAS_MAX_GROUP] = {nullptr, nullptr, nullptr, nullptr};
     for (int k = 0; k < n; ++k) {
         sl[k] = &c->slots[(c->head + c->inflight + k) % c->n_slots];

@@ -1303,7 +1303,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
     const unsigned long long *g = f.keys + beg;
     if (n >= 0) PH_LAP(0);   // (n: the dependent loads of the tile's index and its offsets have returned)
     // the tile kernel's waves issue ahead of the co-resident binning waves of the next frames (+1.2 % frames/s at config 3:
-    // what a step costs is the tile kernel's slot time; the reverse priority costs 0.5 %)
+    // what a step costs is the tile kernel's slot time, docs/EXPERIMENTS.md s5.30; the reverse priority costs 0.5 %)
     __builtin_amdgcn_s_setprio(3);
 
     if (n > 0 && n <= CH) {

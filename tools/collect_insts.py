@@ -23,7 +23,7 @@ d = {"workload": "BASELINE config 3, bench.py (two views per step): mean over th
      "lds_insts_per_launch": mean.get("SQ_INSTS_LDS", 0.0), "smem_insts_per_launch": mean.get("SQ_INSTS_SMEM", 0.0),
      "launches": len(acc.get("SQ_INSTS_VALU", [])),
      "composited_pixel_splats": composited, "staged_entries": int(staged.group(1)) if staged else 0,
-     "valu_per_composited_pixel_splat": 26,
-     "valu_per_composited_pixel_splat_note": "sigma 5 + clamp 1 + exp 9 + alpha 2 + skip test / weight 3 + T 1 + half a stop test + accumulate 4, rounded up (the loop's instructions for one pixel-splat pair on a trip where no pixel terminates, at full lane use)"}
+     "valu_per_composited_pixel_splat": 28,
+     "valu_per_composited_pixel_splat_note": "sigma 7 + clamp 1 + exp 9 + alpha 2 + skip test / weight 3 + T 1 + half a stop test + accumulate 4, rounded up (the loop's instructions for one pixel-splat pair on a trip where no pixel terminates, at full lane use)"}
 out.write_text(json.dumps(d, indent=1))
 print(json.dumps(d, indent=1))
