@@ -92,6 +92,8 @@ struct SasFrame {
     long long cap;
     int seg;                   // > 0: single-pass binning, tile t's keys (and ids) live at [t * seg, t * seg + count); cap = tiles * seg
     int cull;                  // (single-pass binning only) 1: tiles of its rectangle a Gaussian cannot reach are left out of the lists
+    int group_fill;            // 1 (frames that share the chip with others: SAS_ASYNC, batches): ONE workgroup paints the four tiles of an all-empty tile group;
+                               // 0 (a blocking frame alone on the GPU): every tile has its own workgroup -- the kernel's end is shorter, its slot time larger
     int keep_info;             // 1: the geometry role writes info[] (two-pass frames: k_scatter reads it; the parity hook; -DSAS_TUNE_STATS builds).
                                // Single-pass product frames skip it: nothing on the device reads it, 16 B per Gaussian less to write
     unsigned *stats;           // [8] device counters

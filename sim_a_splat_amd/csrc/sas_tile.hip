@@ -1185,6 +1185,9 @@ constexpr int kRankMax = SAS_TUNE_RANKMAX;   // largest depth bucket a chunk is 
 // layout pass + the per-chunk depth gathers cost 3 % at config 2, lists of ~4 000).
 constexpr int kPartitionMin = SAS_TUNE_PARTMIN;
 constexpr int kLazyThreads = 256;
+#ifndef SAS_EMPTY_GROUPS_OFF
+#define SAS_EMPTY_GROUPS_OFF 0   // A/B builds: 1 = every tile of an all-empty group takes a workgroup of its own (round 4)
+#endif
 
 // Lay the keys of buckets >= b_first out by bucket: slot ids into `ids` at the positions handed out by the
 // per-bucket cursors `cur` (LDS, preset to each bucket's start).  A real call, not inlined: it runs once for
@@ -1247,6 +1250,35 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         if (wg >= (unsigned)f.n_tiles) return;
         tile = f.tile_order[wg];
 #else
+        // Groups whose four tiles are all empty are the last class of the order; class_cursor[15] says where it starts.  Such a
+        // group costs ONE workgroup that paints its four tiles' background (the other three leave after a scalar load), instead
+        // of four that each fetch their tile, its count and paint 256 pixels: the empty tiles were 6 % of the kernel's slot time
+        // (3 880 of config 3's 8 160 tiles), which is what frames in flight compete for.  A blocking frame alone on the GPU keeps a
+        // workgroup per tile (SasFrame::group_fill): there the kernel's END counts, and four tiles in a row lengthen it.
+        if (!QUAD && !SAS_EMPTY_GROUPS_OFF && f.group_fill && (int)(wg >> 2) >= f.class_cursor[15]) {
+            if (wg & 3u) return;
+            const int g4 = 4 * f.tile_order[wg >> 2];
+            const SasCam &cc = P.cam;
+            const SasOutputs &oo = P.out;
+            const int tid_ = threadIdx.x, lane_ = tid_ & 63, wv_ = tid_ >> 6;
+            int ox_, oy_;
+            pixel_of(wv_, lane_, ox_, oy_);
+            const bool pack4 = oo.rgb8 && (cc.W & 3) == 0 && ((size_t)oo.rgb8 & 3) == 0;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int t = g4 + q;
+                if (t >= f.n_tiles) break;
+                const int tx_ = t % cc.tw, ty_ = t / cc.tw;
+                const int ix_ = tx_ * SAS_TILE + ox_, iy_ = ty_ * SAS_TILE + oy_;
+                const bool in_ = ix_ < cc.W && iy_ < cc.H;
+                const PixState p0 = pix_init(in_, ox_);
+                unsigned packed_;
+                const float ED_ = write_pixel<true>(oo, p0, in_, ix_, iy_, cc.W, packed_, pack4);
+                if (oo.rgb8_host) store_rows_to_host<16>(oo.rgb8_host, cc.W, tx_ * SAS_TILE, ty_ * SAS_TILE, ox_, oy_, true, packed_, s_raw);
+                if (WANT_MAX) store_tile_max(f, t, ED_, s_wmax);
+            }
+            return;
+        }
         tile = 4 * f.tile_order[wg >> 2] + (int)(wg & 3u);
         if (tile >= f.n_tiles) return;
 #endif
