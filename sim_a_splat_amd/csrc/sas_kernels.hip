@@ -129,7 +129,7 @@ DEV void sh_to_color(const float *sh, float dx, float dy, float dz, float *rgb)
 // kernel (two evaluations per lane) then fits the 64 registers of eight waves per SIMD.  A channel's sum is the same chain in
 // coefficient order as sh_to_color's: identical bits.
 struct ShHalf {
-    float x, y, z, z2, fC1, fS1;
+    float x, y, z;   // (z2, fC1, fS1 are three multiplications away: recomputed by the second half rather than carried)
     float r[3];
 };
 DEV void sh3_first(const float *a /* floats 0 .. 23 */, float dx, float dy, float dz, ShHalf &S)
@@ -143,14 +143,13 @@ DEV void sh3_first(const float *a /* floats 0 .. 23 */, float dx, float dy, floa
         float t = fma_(-x, a[3 * 3 + c], fma_(z, a[2 * 3 + c], (-y) * a[1 * 3 + c]));
         S.r[c] = fma_(0.48860251190292f, t, r);
     }
-    S.z2 = z * z;
-    S.fC1 = fma_(x, x, -(y * y));
-    S.fS1 = 2.0f * x * y;
+    const float z2 = z * z;
+    const float fS1 = 2.0f * x * y;
     const float fTmp0B = -1.092548430592079f * z;
-    const float pSH6 = fma_(0.9461746957575601f, S.z2, -0.3153915652525201f);
+    const float pSH6 = fma_(0.9461746957575601f, z2, -0.3153915652525201f);
     const float pSH7 = fTmp0B * x;
     const float pSH5 = fTmp0B * y;
-    const float pSH4 = 0.5462742152960395f * S.fS1;
+    const float pSH4 = 0.5462742152960395f * fS1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float r = S.r[c];
@@ -163,7 +162,8 @@ DEV void sh3_first(const float *a /* floats 0 .. 23 */, float dx, float dy, floa
 }
 DEV void sh3_second(const float *b /* floats 24 .. 47: coefficient k of channel c at b[3 (k - 8) + c] */, const ShHalf &S, float *rgb)
 {
-    const float x = S.x, y = S.y, z = S.z, z2 = S.z2, fC1 = S.fC1, fS1 = S.fS1;
+    const float x = S.x, y = S.y, z = S.z;
+    const float z2 = z * z, fC1 = fma_(x, x, -(y * y)), fS1 = 2.0f * x * y;   // (the same operations on the same values as in sh_to_color)
     const float pSH8 = 0.5462742152960395f * fC1;
     const float fTmp0C = fma_(-2.285228997322329f, z2, 0.4570457994644658f);
     const float fTmp1B = 1.445305721320277f * z;
@@ -1250,6 +1250,9 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
         for (int v = 0; v < NV; ++v) {
             const SasCam &c = vs.cam[v];
             sh3_first(a, m[0] - c.campos[0], m[1] - c.campos[1], m[2] - c.campos[2], S[v]);
+            // (pin the half-way state HERE: hipcc otherwise sinks the first half's arithmetic below the second half's loads -- its
+            // results are first used there -- and all 48 coefficients are in registers at once after all)
+            asm volatile("" : "+v"(S[v].x), "+v"(S[v].y), "+v"(S[v].z), "+v"(S[v].r[0]), "+v"(S[v].r[1]), "+v"(S[v].r[2]));
         }
         __builtin_amdgcn_sched_barrier(0);   // (the second half's loads stay behind the first half's arithmetic: that is the point)
         float b[24];
