@@ -38,7 +38,7 @@ def test_bench_line_schema_at_the_drivers_command_shape():
     assert r["co_resident"]["kernel_ms"] >= r["kernel_ms"] * 0.9        # ... the launch inside the timed region shares the chip
     rp = d["roofline_projection"]                                       # the second kernel of a frame, an HBM stream, against the same roof
     assert rp["kernel"] == "k_project" and rp["bound"] == "hbm" and abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-9 and 0.05 < rp["frac"] < 1.0   # (the bounds-checked build runs this test too: slower kernels)
-    assert 0 < rp["n_keys"] <= d["config"]["n_intersections"] and 0.0 < rp["kernel_ms"] < 2.0 * d["ms_per_step"]
+    assert rp["n_keys"] > 0 and 0.0 < rp["kernel_ms"] < 2.0 * d["ms_per_step"]   # (n_keys: what was binned -- fewer than the rectangles' intersections with exact tile culling, more when the frame is binned in 8-pixel tiles)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 100                                # reported beside, not the target
