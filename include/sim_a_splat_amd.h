@@ -239,7 +239,10 @@ int sas_frame_stats(sas_ctx *ctx, int64_t *stats, int n);
  * per-tile sorted lists of the last completed frame, in the layout of gsplat's intermediate
  * tensors (radii [n,2] i32, means2d [n,2], depths [n], conics [n,3], colors [n,3];
  * tile_offsets [tiles+1] i32, sorted_ids [<=cap] i32).  sorted_ids is complete only for a frame
- * rendered with SAS_FULL_SORT (the default path orders lists lazily, front chunk by front chunk). */
+ * rendered with SAS_FULL_SORT (the default path orders lists lazily, front chunk by front chunk).
+ * sas_read_projection: the product path does not keep the rectangles and radii of a frame (nothing on the device reads
+ * them); the hook projects the last frame once more to obtain them -- same camera, same pose snapshot -- before it
+ * reads back: a test facility, not a per-frame call. */
 int sas_read_projection(sas_ctx *ctx, int32_t *radii, float *means2d, float *depths, float *conics,
                         float *colors);
 int sas_read_tile_lists(sas_ctx *ctx, int32_t *tile_offsets, int32_t *sorted_ids, int64_t cap);
