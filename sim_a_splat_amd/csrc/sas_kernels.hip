@@ -816,12 +816,11 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
     PL_LAP(13);
 }
 
-// SINGLE: single-pass binning (the product path) -- every count is in tile_count, there are no offset / cursor tables.
-// The tail's registers are the PROJECTION's registers (the kernel's allocation is the maximum over its roles): the
-// single-pass form reads bursts of 16 tiles (4 x 16-byte loads in flight), the two-pass form, which reads two arrays,
-// bursts of 8 -- either way 16 registers of counts, so that the tail stays below the geometry role's own 59-64.
-template <bool SINGLE>
-DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
+// The tail of a TWO-PASS frame (SAS_FULL_SORT, SAS_DIRECT=0, frames whose segments exceed the budget): offsets, cursors of the
+// `big` entries, class sizes; the tiles are put in order by k_scatter's front workgroups.  Its registers are the PROJECTION's
+// registers (the kernel's allocation is the maximum over its roles): it reads its two count arrays in bursts of 8 tiles --
+// 16 registers of counts -- so that it stays below the geometry role's own 59-64.
+DEV void scan_tail_two_pass(const SasFrame *fp, int *lds /* >= 1568 ints */)
 {
     const SasFrame &f = *fp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -832,7 +831,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
     const int t0 = tid * per;
     const int4 *win4 = reinterpret_cast<const int4 *>(f.tile_count + t0);
     const int4 *big4 = reinterpret_cast<const int4 *>(f.tile_big + t0);
-    constexpr int NB = SINGLE ? 4 : 2;   // 16-byte loads per array and burst
+    constexpr int NB = 2;   // 16-byte loads per array and burst
     s_bins[tid] = 0;
     s_bins[256 + tid] = 0;
     // ---- phase 1: totals
@@ -848,7 +847,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         for (int j = 0; j < NB; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = (in && !SINGLE) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);   // (single-pass binning counts everything in tile_count)
+            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -886,14 +885,14 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         for (int j = 0; j < NB; ++j) {
             const bool in = k0 + 4 * j < per;
             c[j] = in ? win4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
-            g[j] = (in && !SINGLE) ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
+            g[j] = in ? big4[(k0 >> 2) + j] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int k = k0 + 4 * j, t = t0 + k;
             if (k >= per || t >= tiles) continue;
             const int cc[4] = {c[j].x + g[j].x, c[j].y + g[j].y, c[j].z + g[j].z, c[j].w + g[j].w};
-            if constexpr (!SINGLE) {
+            {
                 const int cw[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
                 const int4 o = make_int4(run, run + cc[0], run + cc[0] + cc[1], run + cc[0] + cc[1] + cc[2]);
                 run = o.w + cc[3];
@@ -920,50 +919,6 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         s_w[tid] = sum;
     }
     __syncthreads();
-    if constexpr (SINGLE) {
-        // ---- phase 3 (single-pass binning: there is no scatter launch whose front workgroups could do it): the tile ORDER.
-        // Position of a tile = its class's start + the tiles of the class counted by lower copies of the class's bin +
-        // its rank among the tiles this copy counted (a second round of LDS atomics on fresh counters: the order inside a
-        // class is free).  The counts are read a third time (L2 hits).
-        int *s_off = lds + 16 + 512, *s_rank = s_off + 512, *s_cstart = s_rank + 512;
-        if (tid == 0) {   // starts of the 16 classes (s_w[j]: size of class entry j)
-            int start = 0;
-            for (int j = 0; j < 16; ++j) { s_cstart[j] = start; start += s_w[j]; }
-        }
-        __syncthreads();
-        // per (class, copy): exclusive prefix over the class's 32 copies + the class's start; two classes per wave, two rounds
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int idx = 256 * half + tid;
-            const int v = s_bins[idx];
-            int incl = v;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const int o = __shfl_up(incl, d, 32);
-                if ((lane & 31) >= d) incl += o;
-            }
-            s_off[idx] = s_cstart[idx >> 5] + incl - v;
-            s_rank[idx] = 0;
-        }
-        __syncthreads();
-        // (four tiles per step, not the 16-tile bursts of phases 1 and 2: this pass runs in single-pass frames, whose counts
-        // are all in tile_count, and its registers are the PROJECTION's registers -- bursts cost k_project<3,1> 11 of them
-        // and two waves per SIMD)
-#pragma unroll 1
-        for (int k = 0; k < per; k += 4) {
-            const int t = t0 + k;
-            if (t >= tiles) break;
-            const int4 c = win4[k >> 2];
-            const int cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (t + q < tiles) {
-                    const int b = (15 - len_class(cc[q])) * 32 + (lane & 31);
-                    const int pos = s_off[b] + atomicAdd(&s_rank[b], 1);
-                    if (SAS_IN(pos, tiles, 105)) f.tile_order[pos] = t + q;
-                }
-        }
-    }
     if (tid == 0) {
         int start = 0;
         for (int k = 0; k < 16; ++k) {   // descending classes: entry k = class 15 - k
@@ -981,7 +936,7 @@ DEV void scan_tail(const SasFrame *fp, int *lds /* >= 1568 ints */)
         unsigned *h = f.stats_host;      // the statistics, straight to pinned host memory
         h[0] = (unsigned)nvis_all;
         h[1] = (unsigned)carry;
-        h[2] = (SINGLE ? maxlen_all > f.seg : (long long)carry > f.cap) ? 1u : 0u;   // single-pass binning: a tile outgrew its segment
+        h[2] = (long long)carry > f.cap ? 1u : 0u;   // the compact lists outgrew the key buffer
         h[3] = f.wg_isect16 ? (unsigned)n16_all : (unsigned)carry;   // intersections with the contract's 16-pixel tiles
         h[4] = (unsigned)maxlen_all;
         h[5] = f.stats[5];
@@ -1196,7 +1151,7 @@ DEV void geom_role(const SasScene &s, const SasCam &c, const SasFrame &f, unsign
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the tail's loads below are not served from a stale cache line
 #ifndef SAS_TUNE_NOTAIL
     if (f.seg > 0) scan_tail_single(&f, s_hist, pl_wg_, pl_t_);   // (uniform)
-    else scan_tail<false>(&f, s_hist);
+    else scan_tail_two_pass(&f, s_hist);
 #endif
     PL_LAP(9);
 #ifdef SAS_TUNE_PTIME
