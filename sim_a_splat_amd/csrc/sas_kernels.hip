@@ -1265,11 +1265,12 @@ struct Role {
 // workgroup at 70).  Dispatch index -> chunk is a transpose over kSpreadRows rows: consecutive blocks are n_wg / 16
 // chunks apart, any run of heavy chunks is spread over the whole launch.  (Blocks whose chunk lies past the end leave.)
 constexpr unsigned kSpreadRows = 16;
-DEV unsigned spread_cols(unsigned n_wg) { return (n_wg + kSpreadRows - 1u) / kSpreadRows; }
-DEV unsigned spread_chunk(unsigned gi, unsigned n_wg) { return (gi % kSpreadRows) * spread_cols(n_wg) + gi / kSpreadRows; }
-DEV Role block_role(unsigned b, unsigned n_geo, unsigned mix_k)
+__host__ DEV unsigned spread_cols(unsigned n_wg) { return (n_wg + kSpreadRows - 1u) / kSpreadRows; }
+__host__ DEV unsigned spread_chunk(unsigned gi, unsigned n_wg) { return (gi % kSpreadRows) * spread_cols(n_wg) + gi / kSpreadRows; }
+__host__ DEV Role block_role(unsigned b, unsigned n_geo, unsigned mix_k)
 {
-    const unsigned g0 = min(n_geo, (b * mix_k + 7u) >> 3), g1 = min(n_geo, ((b + 1u) * mix_k + 7u) >> 3);
+    const unsigned c0 = (b * mix_k + 7u) >> 3, c1 = ((b + 1u) * mix_k + 7u) >> 3;
+    const unsigned g0 = c0 < n_geo ? c0 : n_geo, g1 = c1 < n_geo ? c1 : n_geo;
     Role r;
     r.geom = g1 > g0;
     r.idx = r.geom ? g0 : b - g0;
@@ -1512,6 +1513,25 @@ static int project_mix(int nv, unsigned n_wg)
     const int kmin = (int)((8u * n_geo + total - 1u) / total);
     const int k = env > 0 ? env : (nv == 1 ? 5 : 7);
     return k < kmin ? kmin : (k > 8 ? 8 : k);
+}
+
+// Test hook (CPU, no GPU needed): what block `b` of a projection launch over n_wg chunks of 256 Gaussians and nv views does --
+// through the very functions the kernel and its launcher use.  out = {grid size, mix_k, is geometry, chunk, view}; chunk >= n_wg:
+// the block leaves at once (padding of the transposed dispatch).  tests/test_host_logic.py holds the mapping to "every
+// (chunk, view) has exactly one geometry block, every chunk exactly one colour block".
+extern "C" int sas_debug_projection_block(unsigned b, unsigned n_wg, int nv, unsigned *out)
+{
+    if (!out || n_wg == 0 || nv < 1 || nv > 2) return -1;
+    const unsigned n_geo = (unsigned)nv * sas_spread_blocks(n_wg), grid = n_geo + n_wg;
+    const unsigned mix = (unsigned)project_mix(nv, n_wg);
+    out[0] = grid;
+    out[1] = mix;
+    if (b >= grid) return -2;
+    const Role r = block_role(b, (unsigned)nv * kSpreadRows * spread_cols(n_wg), mix);
+    out[2] = r.geom ? 1u : 0u;
+    out[3] = r.geom ? spread_chunk(nv == 1 ? r.idx : r.idx >> 1, n_wg) : r.idx;
+    out[4] = (r.geom && nv == 2) ? (r.idx & 1u) : 0u;
+    return 0;
 }
 
 template <int NV>
