@@ -40,16 +40,17 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
 
 
 def broadcast_scene(scene, rank: int, world: int, src: int = 0, device: Optional[torch.device] = None,
-                    fields: Sequence[str] = ("means", "quats", "scales", "opacities", "sh", "group_id")):
+                    fields: Sequence[str] = ("means", "quats", "scales", "opacities", "sh", "group_id"), collective: Optional[bool] = None):
     """The scene, replicated: rank ``src`` passes an object with the array attributes ``fields`` (NumPy arrays or tensors; a
     ``None`` attribute is skipped) plus ``sh_degree``; every other rank passes ``None`` and RECEIVES it -- one
     ``dist.broadcast`` per array over the backend (RCCL: device tensors over xGMI, ``ncclBroadcast``; gloo: host tensors),
     instead of every rank reading or generating its own copy (SURVEY.md 8e: "Scene broadcast at load: ncclBroadcast once";
     1 M Gaussians = 236 MB).  Returns a ``types.SimpleNamespace`` with the same attributes as tensors on ``device`` (RCCL) or
-    on the host (gloo) -- ``Rasterizer.upload`` takes either -- and ``n``, ``sh_degree``.  A world of one returns ``scene``."""
+    on the host (gloo) -- ``Rasterizer.upload`` takes either -- and ``n``, ``sh_degree``.  A world of one returns ``scene``
+    (``collective=True``: it runs the broadcasts through the backend all the same: the one-GPU rehearsal of the RCCL path)."""
     import types
     import numpy as np
-    if world <= 1 or not dist.is_initialized():
+    if (world <= 1 and not collective) or not dist.is_initialized():
         return scene
     on_device = dist.get_backend() == "nccl"
     dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_device else torch.device("cpu")

@@ -25,6 +25,7 @@ def test_rccl_gathers_device_frames_at_world_size_one():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["backend"] == "nccl" and line["world"] == 1 and line["device_tensors"]
     assert line["pipeline_bit_equal"] and line["gather_frames_bit_equal"] and line["float_frame_bit_equal"], line
+    assert line["scene_broadcast_bit_equal"], line      # the scene replicated by RCCL's broadcast (device tensors) renders the same frame
     assert line["vec_env_bit_equal"], line      # SplatVecEnv's observations gathered through RCCL == its single-process ones
     # ... and its frames never bounce through the host on the way: no upload of a finished frame, one download per step on the root
     assert line["vec_env_device_resident"], line

@@ -98,10 +98,20 @@ vec_ok = vec_ok and seen > 0          # (the viewport camera looks at the scene;
 vec_device_resident = via_rccl._device_payload and via_rccl.h2d_frame_copies == 0 and via_rccl.d2h_frame_copies == 3 \
     and plain.h2d_frame_copies == 0 and plain.d2h_frame_copies == 0
 
+# ---- the scene broadcast (ncclBroadcast of device tensors; SURVEY.md 8e "Scene broadcast at load") ---------------------------------
+bs = D.broadcast_scene(sc, rank, world, device=dev, collective=True)
+scene_ok = bs.n == sc.n and all(getattr(bs, k).is_cuda and np.array_equal(getattr(bs, k).cpu().numpy(), getattr(sc, k))
+                                for k in ("means", "quats", "scales", "opacities", "sh", "group_id"))
+r2 = Rasterizer(dev.index)
+r2.upload(bs.means, bs.opacities, bs.sh, quats=bs.quats, scales=bs.scales, sh_degree=bs.sh_degree, group_id=bs.group_id, n_groups=4)
+r.set_group_poses(poses[0]); r2.set_group_poses(poses[0])
+scene_ok = scene_ok and torch.equal(r2.render(Vs[0], Ks[0], W, H, BG, want=("rgb8",))["rgb8"], r.render(Vs[0], Ks[0], W, H, BG, want=("rgb8",))["rgb8"])
+r2.close()
+
 ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else "?"
 print(json.dumps({"backend": dist.get_backend(), "world": world, "rccl_version": ver, "steps": STEPS, "views_per_step": V,
                   "pipeline_bit_equal": bool(pipeline_ok), "gather_frames_bit_equal": bool(helper_ok), "float_frame_bit_equal": bool(float_ok),
-                  "vec_env_bit_equal": bool(vec_ok), "vec_env_device_resident": bool(vec_device_resident),
+                  "scene_broadcast_bit_equal": bool(scene_ok), "vec_env_bit_equal": bool(vec_ok), "vec_env_device_resident": bool(vec_device_resident),
                   "vec_env_copies": {"h2d": via_rccl.h2d_frame_copies, "d2h": via_rccl.d2h_frame_copies}, "device_tensors": True}))
 r.close()
 dist.destroy_process_group()
