@@ -1795,14 +1795,22 @@ void sas_launch_blend(hipStream_t st, const SasScene &s, int tiles, const SasPar
 // Production path: lazy ordering + compositing of every tile in one launch.
 // quad: frames of a few hundred tiles, binned in 8-pixel tiles by their projection (`tiles` counts those): one
 // workgroup per 8x8 quadrant (pixel_of_quad); exact exponential only (SAS_FAST_EXP frames take the ordinary layout).
+// experiments: SAS_TILE_DYN_LDS = bytes of unused dynamic LDS per tile workgroup (the compiled kernel, fewer workgroups per CU:
+// 6656 -> four, 14000 -> three; profiles/r05_ab_tile_workgroups_per_cu.txt)
+static unsigned lazy_dyn_lds()
+{
+    static const unsigned v = [] { const char *e = getenv("SAS_TILE_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    return v;
+}
+
 template <bool FAST, bool WMAX, bool QUAD>
 static void launch_lazy(hipStream_t st, unsigned grid, const SasParams &P, const SasFrame &f, long long n, const int *perm,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
-        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), 0, st, e0, e1, 0, P, f, n, perm);
+        hipExtLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), lazy_dyn_lds(), st, e0, e1, 0, P, f, n, perm);
     else
-        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), 0, st, P, f, n, perm);
+        hipLaunchKernelGGL((k_tile_lazy<FAST, WMAX, QUAD>), dim3(grid), dim3(kLazyThreads), lazy_dyn_lds(), st, P, f, n, perm);
 }
 
 bool sas_tiles_lazy_quad_ok(bool fast_exp) { return !fast_exp; }
@@ -1828,9 +1836,9 @@ template <bool FAST, bool WMAX, bool QUAD>
 static void launch_lazy_multi(hipStream_t st, dim3 grid, const SasMulti &mf, long long n, const int *perm, hipEvent_t e0, hipEvent_t e1)
 {
     if (e0 && e1)
-        hipExtLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), 0, st, e0, e1, 0, mf, n, perm);
+        hipExtLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), lazy_dyn_lds(), st, e0, e1, 0, mf, n, perm);
     else
-        hipLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), 0, st, mf, n, perm);
+        hipLaunchKernelGGL((k_tile_lazy_multi<FAST, WMAX, QUAD>), grid, dim3(kLazyThreads), lazy_dyn_lds(), st, mf, n, perm);
 }
 
 void sas_launch_tiles_lazy_multi(hipStream_t st, const SasScene &s, int tiles, const SasMulti &mf, bool fast_exp, bool want_max,

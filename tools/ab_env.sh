@@ -1,7 +1,10 @@
 #!/bin/bash
-# bench frames/s (300 steps and the driver's 20) under environment settings, each run twice:  tools/ab_env.sh "SAS_CU_SPLIT=32" "SAS_CU_SPLIT=48" ""
-for e in "$@" "$@"; do
-  a=$(env $e timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras --steps 300 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['cold_start']['value']), round(d['roofline']['kernel_ms'],4))")
-  b=$(env $e timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['door_a_sync']['value']), round(d['single_view_async']['value']))")
-  echo "[$e] steps300: value cold tile_ms = $a | steps20: value doorA single = $b"
+# Isolated kernel times (stage_probe, config 3) and the pair bench of the in-tree library under values of ONE environment knob,
+# on one GPU box, the list twice:   tools/ab_env.sh VAR value...      ("-" = unset)
+var=$1; shift
+for val in "$@" "$@"; do
+  if [ "$val" = "-" ]; then unset $var; else export $var=$val; fi
+  st=$(timeout -k 10 200 python tools/stage_probe.py --cfg 3 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['stage_ms']['project'],4), round(d['stage_ms']['blend'],4), round(d['stage_ms']['total'],4))")
+  fps=$(timeout -k 10 300 python bench.py --no-cpu-baseline --steps 300 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['door_a_sync']['value'],1), round(d['door_a_async']['value'],1), round(d['cold_start']['value'],1))")
+  echo "$var=$val project_ms,tile_ms,total_ms=$st bench_fps,door_a_sync,door_a_async,cold=$fps"
 done
