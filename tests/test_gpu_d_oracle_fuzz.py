@@ -18,4 +18,4 @@ def test_forty_drawn_cases_are_bit_equal_to_the_oracle(rasterizer):
         diffs = fz.run_case(rasterizer, c)
         assert not diffs, (fz.describe(c), diffs)
         entries.add(c["entry"]); degrees.add(c["deg"])
-    assert entries == {"single", "batch", "posed", "host"} and degrees == {-1, 0, 1, 2, 3}      # the slice reaches every arm
+    assert entries == {"single", "batch", "posed", "host", "pipelined"} and degrees == {-1, 0, 1, 2, 3}      # the slice reaches every arm

@@ -8,7 +8,8 @@ bit for bit (the arithmetic contract); the seeded pytest cases fix 
   camera     ragged image sizes from 17x17, focal length, radius (a camera INSIDE the cloud crosses the near plane), off-centre
              principal points
   entry      one blocking frame, a batch of 2-3 views (the pair projection), a batch with one pose set per view, host-delivered
-             uint8 frames; depth fill on or off
+             uint8 frames, and PIPELINED steps (3-6 steps enqueued without waiting -- single frames or batches, new group poses
+             before every step, four frames in flight over the slot ring -- then one wait); depth fill on or off
 
     python tests/tools/oracle_fuzz.py [n_seeds] [first_seed]          (exit code 1 on the first difference; prints each case)
 
@@ -57,7 +58,21 @@ def draw_case(seed: int) -> dict:
     entry = "single" if n_views == 1 else str(rng.choice(["batch", "batch", "posed", "host"]))
     if n_groups == 0 and entry == "posed":
         entry = "batch"
-    poses = [random_group_poses(n_groups, seed=99_000 + 7 * seed + v, max_angle=0.6, max_shift=0.3) for v in range(n_views)] if n_groups else None
+    steps = 1
+    if rng.random() < 0.2:
+        entry, steps = "pipelined", int(rng.integers(3, 7))
+    poses = [random_group_poses(n_groups, seed=99_000 + 7 * seed + v, max_angle=0.6, max_shift=0.3) for v in range(max(n_views, steps))] if n_groups else None
+    if entry == "pipelined":     # every step looks from its own place
+        yaw0 = float(rng.uniform(0, 2 * np.pi))
+        step_cams = []
+        for s_ in range(steps):
+            row = []
+            for v in range(n_views):
+                a = yaw0 + 0.7 * s_ + 2.1 * v
+                row.append(Camera(look_at_viewmat((3.0 * np.sin(a), 0.3 * s_ - 0.5, 3.0 * np.cos(a))), cams[v].K, W, H))
+            step_cams.append(row)
+        return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H,
+                    steps=steps, step_cams=step_cams)
     return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H)
 
 
@@ -88,6 +103,8 @@ def run_case(r, c: dict) -> list:
     Vs, Ks = np.stack([cm.viewmat for cm in cams]), np.stack([cm.K for cm in cams])
     view_pose = [None] * len(cams)
     got = []
+    if c["entry"] == "pipelined":
+        return run_pipelined(r, c, inp, gid)
     if c["entry"] == "single":
         if c["poses"]:
             r.set_group_poses(c["poses"][0]); view_pose[0] = c["poses"][0]
@@ -121,9 +138,41 @@ def run_case(r, c: dict) -> list:
     return diffs
 
 
+def run_pipelined(r, c: dict, inp: dict, gid) -> list:
+    """c['steps'] steps enqueued back to back (block=False), each into its own output tensors and after its own set_group_poses; one
+    wait at the end; then every frame of every step against the oracle."""
+    import torch
+    W, H, fill, sc = c["W"], c["H"], c["fill"], c["scene"]
+    outs = []
+    for s_ in range(c["steps"]):
+        row = c["step_cams"][s_]
+        if c["poses"]:
+            r.set_group_poses(c["poses"][s_])
+        if len(row) == 1:
+            o = r.render(row[0].viewmat, row[0].K, W, H, BG, want=KEYS, depth_fill_max=fill, block=False)
+            outs.append({k: v[None] for k, v in o.items()})
+        else:
+            outs.append(r.render_batch(np.stack([cm.viewmat for cm in row]), np.stack([cm.K for cm in row]), W, H, BG, want=KEYS, depth_fill_max=fill,
+                                       block=False))
+    r.wait()
+    torch.cuda.synchronize()
+    diffs = []
+    for s_ in range(c["steps"]):
+        for i, cm in enumerate(c["step_cams"][s_]):
+            ref = oracle.render(sc.means, sc.opacities, inp["colors"], cm.viewmat, cm.K, W, H, quats=inp["quats"], scales=inp["scales"], cov6=inp["cov6"],
+                                sh_degree=c["deg"], group_id=gid, group_Rt=c["poses"][s_] if c["poses"] else None, background=BG,
+                                depth_mode=1 if fill else 0, want_rgb8=True)
+            for k in KEYS:
+                g = outs[s_][k][i].cpu().numpy()
+                if not np.array_equal(g, ref[k]):
+                    d = np.abs(g.astype(np.float64) - ref[k].astype(np.float64))
+                    diffs.append(f"step {s_} view {i} {k}: {int((d > 0).sum())} values differ, max {d.max():.3e}")
+    return diffs
+
+
 def describe(c: dict) -> str:
     return (f"seed {c['seed']}: n={c['scene'].means.shape[0]} degree={c['deg']} groups={c['n_groups']} {c['W']}x{c['H']} views={len(c['cams'])} "
-            f"entry={c['entry']} fill={c['fill']}")
+            f"entry={c['entry']}{'x%d' % c['steps'] if c['entry'] == 'pipelined' else ''} fill={c['fill']}")
 
 
 def main(argv) -> int:
