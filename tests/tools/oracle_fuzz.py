@@ -187,6 +187,15 @@ def main(argv) -> int:
         st = r.stats()
         print(describe(c), f"max_list={st['max_tile_len']} ->", "bit-equal" if not diffs else "DIFFERENT: " + "; ".join(diffs), flush=True)
         bad += bool(diffs)
+    from sim_a_splat_amd import _capi
+    L = _capi.lib()
+    if hasattr(L, "sas_debug_bounds"):      # the bounds-checked build (SAS_LIB_PATH=variants/lib_bounds.so): every computed index was range-checked
+        import ctypes
+        out = (ctypes.c_uint64 * 4)()
+        L.sas_debug_bounds.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.sas_debug_bounds(out, 0)
+        print(f"bounds-checked build: {out[0]} out-of-range accesses" + (f" (first: code {out[1]}, index {out[2]}, limit {out[3]})" if out[0] else ""))
+        bad += int(out[0] != 0)
     r.close()
     print(f"{n_seeds} cases from seed {first}: " + ("every output bit-equal to the oracle" if bad == 0 else f"{bad} cases differ"))
     return 1 if bad else 0
