@@ -8,8 +8,8 @@ bit for bit (the arithmetic contract); the seeded pytest cases fix 
   camera     ragged image sizes from 17x17, focal length, radius (a camera INSIDE the cloud crosses the near plane), off-centre
              principal points
   entry      one blocking frame, a batch of 2-3 views (the pair projection), a batch with one pose set per view, host-delivered
-             uint8 frames, and PIPELINED steps (3-6 steps enqueued without waiting -- single frames or batches, new group poses
-             before every step, four frames in flight over the slot ring -- then one wait); depth fill on or off
+             uint8 frames, a blocking frame with the complete sorted lists kept, and PIPELINED steps (3-6 steps enqueued without waiting -- single frames or batches, new group poses
+             before every step, four frames in flight over the slot ring -- then one wait); depth fill on or off; nerfstudio's eval background or a drawn one
 
     python tests/tools/oracle_fuzz.py [n_seeds] [first_seed]          (exit code 1 on the first difference; prints each case)
 
@@ -58,6 +58,8 @@ def draw_case(seed: int) -> dict:
     entry = "single" if n_views == 1 else str(rng.choice(["batch", "batch", "posed", "host"]))
     if n_groups == 0 and entry == "posed":
         entry = "batch"
+    bg = BG if rng.random() < 0.5 else tuple(float(v) for v in rng.uniform(0, 1, size=3).astype(np.float32))
+    full_sort = bool(entry == "single" and rng.random() < 0.15)       # complete sorted lists kept (the T4/T5 arrays' path)
     steps = 1
     if rng.random() < 0.2:
         entry, steps = "pipelined", int(rng.integers(3, 7))
@@ -72,8 +74,9 @@ def draw_case(seed: int) -> dict:
                 row.append(Camera(look_at_viewmat((3.0 * np.sin(a), 0.3 * s_ - 0.5, 3.0 * np.cos(a))), cams[v].K, W, H))
             step_cams.append(row)
         return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H,
-                    steps=steps, step_cams=step_cams)
-    return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H)
+                    steps=steps, step_cams=step_cams, bg=bg, full_sort=False)
+    return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H, bg=bg,
+                full_sort=full_sort)
 
 
 def scene_inputs(c: dict) -> dict:
@@ -95,7 +98,7 @@ def scene_inputs(c: dict) -> dict:
 
 def run_case(r, c: dict) -> list:
     """Renders the case on the GPU through its entry point and with the oracle view by view; returns the differences found."""
-    sc, cams, W, H, fill = c["scene"], c["cams"], c["W"], c["H"], c["fill"]
+    sc, cams, W, H, fill, BG = c["scene"], c["cams"], c["W"], c["H"], c["fill"], c["bg"]
     inp = scene_inputs(c)
     gid = sc.group_id if c["n_groups"] else None
     r.upload(sc.means, sc.opacities, inp["colors"], quats=inp["quats"], scales=inp["scales"], covariances=inp["cov"], sh_degree=c["deg"],
@@ -108,7 +111,7 @@ def run_case(r, c: dict) -> list:
     if c["entry"] == "single":
         if c["poses"]:
             r.set_group_poses(c["poses"][0]); view_pose[0] = c["poses"][0]
-        o = r.render(Vs[0], Ks[0], W, H, BG, want=KEYS, depth_fill_max=fill)
+        o = r.render(Vs[0], Ks[0], W, H, BG, want=KEYS, depth_fill_max=fill, full_sort=c["full_sort"])
         got.append({k: v.cpu().numpy() for k, v in o.items()})
     elif c["entry"] == "posed":
         o = r.render_batch(Vs, Ks, W, H, BG, want=KEYS, depth_fill_max=fill, pose_sets=np.stack(c["poses"]), pose_set=list(range(len(cams))))
@@ -142,7 +145,7 @@ def run_pipelined(r, c: dict, inp: dict, gid) -> list:
     """c['steps'] steps enqueued back to back (block=False), each into its own output tensors and after its own set_group_poses; one
     wait at the end; then every frame of every step against the oracle."""
     import torch
-    W, H, fill, sc = c["W"], c["H"], c["fill"], c["scene"]
+    W, H, fill, sc, BG = c["W"], c["H"], c["fill"], c["scene"], c["bg"]
     outs = []
     for s_ in range(c["steps"]):
         row = c["step_cams"][s_]
@@ -172,7 +175,7 @@ def run_pipelined(r, c: dict, inp: dict, gid) -> list:
 
 def describe(c: dict) -> str:
     return (f"seed {c['seed']}: n={c['scene'].means.shape[0]} degree={c['deg']} groups={c['n_groups']} {c['W']}x{c['H']} views={len(c['cams'])} "
-            f"entry={c['entry']}{'x%d' % c['steps'] if c['entry'] == 'pipelined' else ''} fill={c['fill']}")
+            f"entry={c['entry']}{'x%d' % c['steps'] if c['entry'] == 'pipelined' else ''} fill={c['fill']}{' full_sort' if c['full_sort'] else ''}{'' if c['bg'] is BG else ' bg=drawn'}")
 
 
 def main(argv) -> int:
