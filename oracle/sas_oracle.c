@@ -30,6 +30,7 @@
  * (the HIP kernels) reproduces every threshold decision (alpha < 1/255, T <= 1e-4, radius
  * ceil) bit for bit.  DESIGN.md "Arithmetic contract" is the normative text.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -363,6 +364,10 @@ static void project_one(const sas_oracle_scene *s, const cam_t *c, int64_t i, pr
     } else {
         o->rgb[0] = s->colors[3 * i]; o->rgb[1] = s->colors[3 * i + 1]; o->rgb[2] = s->colors[3 * i + 2];
     }
+    /* Contract T2 (round 5): a colour is finite when it leaves the projection (clamped to +-FLT_MAX: the identity on every
+     * finite value, a NaN becomes -FLT_MAX) -- gsplat would carry an Inf to the pixels the Gaussian touches, where the
+     * wrapper's clamp to [0, 1] ends it; the HIP loop adds skipped entries with weight +0, which only finite colours survive. */
+    for (int ch = 0; ch < 3; ++ch) o->rgb[ch] = fminf(fmaxf(o->rgb[ch], -FLT_MAX), FLT_MAX);
 }
 
 /* T3: tile rectangle [x0,x1) x [y0,y1) of a projected Gaussian */

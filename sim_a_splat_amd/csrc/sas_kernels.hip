@@ -384,10 +384,22 @@ DEV void project_view(const SasCam &c, const float *cov, float op, float x, floa
     g.x1 = (int)fminf(fmaxf(ceilf(ttx + trx), 0.0f), twf);
     g.y0 = (int)fminf(fmaxf(floorf(tty - try_), 0.0f), thf);
     g.y1 = (int)fminf(fmaxf(ceilf(tty + try_), 0.0f), thf);
+    // Quad layout (8-pixel bins), opacity NOT <= 1 (no sigmoid produces one: garbage in, but the layouts must agree on it): such a
+    // Gaussian passes the 1/255 test OUTSIDE its 3.33-sigma box, and the contract evaluates it on every pixel of the 16-pixel
+    // tiles of its rectangle -- its 8-pixel rectangle is widened to whole 16-pixel tiles.  (Opacities <= 1 reach nothing outside
+    // the box: alpha <= exp(-3.33^2 / 2) < 1/255.)
+    if (c.tile_px == 8 && !(op <= 1.0f)) {
+        g.x0 &= ~1; g.y0 &= ~1;
+        g.x1 = min((g.x1 + 1) & ~1, c.tw); g.y1 = min((g.y1 + 1) & ~1, c.th);
+    }
     g.mx = mx; g.my = my; g.ca = ca; g.cb = cb; g.ccn = ccn; g.z = z; g.rx = rx; g.ry = ry;
     // conservative skip threshold for the blend stage: alpha >= 1/255 implies
     // sigma <= ln(255 op) + rounding; 1e-3 is > 100x the worst rounding.
-    g.thr = lnq + 1e-3f;
+    // The loop clamps the exponent's argument at -86: once ln(255 o) reaches that, op * exp(-86) >= 1/255 and EVERY pixel passes,
+    // whatever its sigma (opacities beyond 8.7e34, +Inf, NaN -- c_logf reads >= 88 off their exponent bits): nothing may be
+    // culled for such a Gaussian, in the binning or in the block masks.
+    const float t = lnq + 1e-3f;
+    g.thr = t < 85.9f ? t : __builtin_inff();
 }
 
 // ---- exact tile culling (single-pass binning) --------------------------------------------------------------------
@@ -1163,6 +1175,10 @@ DEV void geom_role(const SasScene &s, const SasCam &c, const SasFrame &f, unsign
 // The colour of a Gaussian that the geometry role culls (off screen, degenerate) is computed all the same -- nobody
 // reads it; only what is decided by the mean and the opacity alone is decided here too, with the geometry role's own
 // expressions (near / far plane, transparent), so that scenes mostly behind the camera do not stream their planes.
+// Contract T2 (round 5): a colour is FINITE when it leaves the projection: clamped to +-FLT_MAX (the identity on every finite value; a
+// NaN becomes -FLT_MAX).  The compositing loop adds every staged entry to every pixel of its block with weight +0 where the entry is
+// skipped -- exact for finite colours, but 0 * Inf = NaN would spread one bad SH coefficient over whole blocks.
+DEV float finite_colour(float v) { return fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f); }
 template <int DEG, int NV, typename RowFn>
 DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const float *poses, bool poses_inline, RowFn inline_row)
 {
@@ -1220,7 +1236,7 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
         for (int v = 0; v < NV; ++v) {
             float rgb[3];
             sh3_second(b, S[v], rgb);
-            if (ok[v] && !(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+            if (ok[v] && !(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(finite_colour(rgb[0]), finite_colour(rgb[1]), finite_colour(rgb[2]), 0.0f);
         }
     } else {
         constexpr int KF = DEG >= 0 ? 3 * (DEG + 1) * (DEG + 1) : 4;
@@ -1242,7 +1258,7 @@ DEV void color_role(const SasScene &s, const ProjArgs &vs, unsigned wg, const fl
             } else {
                 rgb[0] = sh[0]; rgb[1] = sh[1]; rgb[2] = sh[2];
             }
-            if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+            if (!(SAS_TUNE_PABL & 8)) vs.f[v].col[SAS_CS * i] = make_float4(finite_colour(rgb[0]), finite_colour(rgb[1]), finite_colour(rgb[2]), 0.0f);
         }
     }
 #ifdef SAS_TUNE_PTIME

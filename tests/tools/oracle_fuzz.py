@@ -4,7 +4,8 @@ bit for bit (the arithmetic contract); the seeded pytest cases fix 
 
   scene      n in {1 .. 120 000}, splat scale over two decades, opacity bands, depth planes (ties), SH degree 0..3,
              final RGB + 3x3 covariances (Door B's input, degree -1), link groups with random rigid poses; one case in
-             sixteen is large (up to 1M Gaussians, up to 1920x1080)
+             sixteen is large (up to 1M Gaussians, up to 1920x1080); one in twelve is POISONED (NaN, +-Inf, 1e+-30, 0 written over
+             1 % of the means / scales / quaternions / opacities)
   camera     ragged image sizes from 17x17, focal length, radius (a camera INSIDE the cloud crosses the near plane), off-centre
              principal points
   entry      one blocking frame, a batch of 2-3 views (the pair projection), a batch with one pose set per view, host-delivered
@@ -42,10 +43,18 @@ def draw_case(seed: int) -> dict:
         sc.means *= np.float32(0.05)                                         # everything in a few tiles: long lists
     deg = int(rng.choice([-1, 0, 1, 2, 3, 3, 3]))
     W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
+    poisoned = bool(rng.random() < 0.08)
     if rng.random() < 0.06:                                                  # now and then a large frame and a large scene
         W, H = int(rng.integers(640, 1921)), int(rng.integers(480, 1081))
         n = int(rng.choice([120000, 500000, 1000000]))
         sc = make_scene(n, seed=88_000 + seed, log_scale_mean=float(rng.uniform(np.log(0.004), np.log(0.03))), n_groups=n_groups)
+    if poisoned:     # non-finite and absurd values in ~1 % of the Gaussians: both sides must cull or clamp them the same way, and the
+        # device must not leave its buffers (the bounds-checked build counts)
+        bad_vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 0.0], np.float32)
+        for arr in (sc.means, sc.scales, sc.quats, sc.opacities):
+            flat = arr.reshape(-1)
+            k = max(1, flat.size // 100)
+            flat[rng.integers(0, flat.size, size=k)] = bad_vals[rng.integers(0, bad_vals.size, size=k)]
     n_views = int(rng.choice([1, 1, 2, 3]))
     cams = []
     for _ in range(n_views):
@@ -74,9 +83,9 @@ def draw_case(seed: int) -> dict:
                 row.append(Camera(look_at_viewmat((3.0 * np.sin(a), 0.3 * s_ - 0.5, 3.0 * np.cos(a))), cams[v].K, W, H))
             step_cams.append(row)
         return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H,
-                    steps=steps, step_cams=step_cams, bg=bg, full_sort=False)
+                    steps=steps, step_cams=step_cams, bg=bg, full_sort=False, poisoned=poisoned)
     return dict(seed=seed, scene=sc, deg=deg, n_groups=n_groups, cams=cams, entry=entry, poses=poses, fill=bool(rng.random() < 0.5), W=W, H=H, bg=bg,
-                full_sort=full_sort)
+                full_sort=full_sort, poisoned=poisoned)
 
 
 def scene_inputs(c: dict) -> dict:
@@ -131,7 +140,7 @@ def run_case(r, c: dict) -> list:
         ref = oracle.render(sc.means, sc.opacities, inp["colors"], cm.viewmat, cm.K, W, H, quats=inp["quats"], scales=inp["scales"], cov6=inp["cov6"],
                             sh_degree=c["deg"], group_id=gid, group_Rt=view_pose[i], background=BG, depth_mode=1 if fill else 0, want_rgb8=True)
         for k, g in got[i].items():
-            if not np.array_equal(g, ref[k]):
+            if not np.array_equal(g, ref[k], equal_nan=g.dtype != np.uint8):
                 d = np.abs(g.astype(np.float64) - ref[k].astype(np.float64))
                 diffs.append(f"view {i} {k}: {int((d > 0).sum())} values differ, max {d.max():.3e}")
         if c["entry"] == "single":
@@ -167,7 +176,7 @@ def run_pipelined(r, c: dict, inp: dict, gid) -> list:
                                 depth_mode=1 if fill else 0, want_rgb8=True)
             for k in KEYS:
                 g = outs[s_][k][i].cpu().numpy()
-                if not np.array_equal(g, ref[k]):
+                if not np.array_equal(g, ref[k], equal_nan=g.dtype != np.uint8):
                     d = np.abs(g.astype(np.float64) - ref[k].astype(np.float64))
                     diffs.append(f"step {s_} view {i} {k}: {int((d > 0).sum())} values differ, max {d.max():.3e}")
     return diffs
@@ -175,7 +184,7 @@ def run_pipelined(r, c: dict, inp: dict, gid) -> list:
 
 def describe(c: dict) -> str:
     return (f"seed {c['seed']}: n={c['scene'].means.shape[0]} degree={c['deg']} groups={c['n_groups']} {c['W']}x{c['H']} views={len(c['cams'])} "
-            f"entry={c['entry']}{'x%d' % c['steps'] if c['entry'] == 'pipelined' else ''} fill={c['fill']}{' full_sort' if c['full_sort'] else ''}{'' if c['bg'] is BG else ' bg=drawn'}")
+            f"entry={c['entry']}{'x%d' % c['steps'] if c['entry'] == 'pipelined' else ''} fill={c['fill']}{' full_sort' if c['full_sort'] else ''}{'' if c['bg'] is BG else ' bg=drawn'}{' POISONED' if c['poisoned'] else ''}")
 
 
 def main(argv) -> int:

@@ -48,6 +48,7 @@ def kept_pairs(o, opacities, width, height, logf):
     A, B, C = (o["conics"][idx, k] for k in range(3))
     op = np.asarray(opacities, np.float32).reshape(-1)[idx]
     thr = np.array([logf(float(np.float32(255.0) * v)) for v in op], np.float32) + np.float32(1e-3)   # (project_view: lnq + 1e-3)
+    thr = np.where(thr < np.float32(85.9), thr, np.float32(np.inf)).astype(np.float32)   # (... and nothing is culled once every pixel passes)
     tw, th = (width + 15) // 16, (height + 15) // 16
     rx, ry = o["radii"][idx, 0].astype(np.float32), o["radii"][idx, 1].astype(np.float32)
     x0 = np.clip(np.floor((mx - rx) / 16), 0, tw).astype(np.int64); x1 = np.clip(np.ceil((mx + rx) / 16), 0, tw).astype(np.int64)
