@@ -5,7 +5,7 @@ bit for bit (the arithmetic contract); the seeded pytest cases fix 
   scene      n in {1 .. 120 000}, splat scale over two decades, opacity bands, depth planes (ties), SH degree 0..3,
              final RGB + 3x3 covariances (Door B's input, degree -1), link groups with random rigid poses; one case in
              sixteen is large (up to 1M Gaussians, up to 1920x1080); one in twelve is POISONED (NaN, +-Inf, 1e+-30, 0 written over
-             1 % of the means / scales / quaternions / opacities)
+             1 % of the means / scales / quaternions / opacities / colours)
   camera     ragged image sizes from 17x17, focal length, radius (a camera INSIDE the cloud crosses the near plane), off-centre
              principal points
   entry      one blocking frame, a batch of 2-3 views (the pair projection), a batch with one pose set per view, host-delivered
@@ -51,7 +51,7 @@ def draw_case(seed: int) -> dict:
     if poisoned:     # non-finite and absurd values in ~1 % of the Gaussians: both sides must cull or clamp them the same way, and the
         # device must not leave its buffers (the bounds-checked build counts)
         bad_vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 0.0], np.float32)
-        for arr in (sc.means, sc.scales, sc.quats, sc.opacities):
+        for arr in (sc.means, sc.scales, sc.quats, sc.opacities, sc.sh):
             flat = arr.reshape(-1)
             k = max(1, flat.size // 100)
             flat[rng.integers(0, flat.size, size=k)] = bad_vals[rng.integers(0, bad_vals.size, size=k)]
@@ -102,7 +102,12 @@ def scene_inputs(c: dict) -> dict:
     cov = (M @ M.transpose(0, 2, 1)).astype(np.float32)
     cov = ((cov + cov.transpose(0, 2, 1)) * np.float32(0.5)).astype(np.float32)
     cov6 = np.ascontiguousarray(np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1))
-    return dict(colors=rng.uniform(0, 1, size=(sc.means.shape[0], 3)).astype(np.float32), quats=None, scales=None, cov=cov, cov6=cov6)
+    colors = rng.uniform(0, 1, size=(sc.means.shape[0], 3)).astype(np.float32)
+    if c["poisoned"]:
+        flat = colors.reshape(-1)
+        k = max(1, flat.size // 100)
+        flat[rng.integers(0, flat.size, size=k)] = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30], np.float32)[rng.integers(0, 5, size=k)]
+    return dict(colors=colors, quats=None, scales=None, cov=cov, cov6=cov6)
 
 
 def run_case(r, c: dict) -> list:
