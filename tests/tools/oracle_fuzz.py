@@ -3,11 +3,12 @@ Every output -- rgb, accumulation, expected depth, uint8 frame, visible and inte
 bit for bit (the arithmetic contract); the seeded pytest cases fix a few dozen inputs, this draws the rest:
 
   scene      n in {1 .. 120 000}, splat scale over two decades, opacity bands, depth planes (ties), SH degree 0..3,
-             final RGB + 3x3 covariances (Door B's input, degree -1), link groups with random rigid poses; one case in
+             final RGB + 3x3 covariances (Door B's input, degree -1), 0 - 200 link groups with random rigid poses; one case in
              sixteen is large (up to 1M Gaussians, up to 1920x1080); one in twelve is POISONED (NaN, +-Inf, 1e+-30, 0 written over
              1 % of the means / scales / quaternions / opacities / colours)
-  camera     ragged image sizes from 17x17, focal length, radius (a camera INSIDE the cloud crosses the near plane), off-centre
-             principal points
+  camera     ragged image sizes from 17x17, strips of one tile row / column thousands of pixels long, focal length (now and then
+             fish-eye-short or telescope-long), radius (a camera INSIDE the cloud crosses the near plane), principal points off
+             centre or outside the image, a view matrix that is not quite a rotation
   entry      one blocking frame, a batch of 2-3 views (the pair projection), a batch with one pose set per view, host-delivered
              uint8 frames, a blocking frame with the complete sorted lists kept, and PIPELINED steps (3-6 steps enqueued without waiting -- single frames or batches, new group poses
              before every step, four frames in flight over the slot ring -- then one wait); depth fill on or off; nerfstudio's eval background or a drawn one
@@ -33,7 +34,7 @@ def draw_case(seed: int) -> dict:
     rng = np.random.default_rng(77_000 + seed)
     n = int(rng.choice([1, 7, 50, 800, 6000, 30000, 120000], p=[0.04, 0.06, 0.1, 0.25, 0.25, 0.2, 0.1]))
     ls = float(rng.uniform(np.log(0.003), np.log(0.3)))
-    n_groups = int(rng.choice([0, 0, 3, 7]))
+    n_groups = int(rng.choice([0, 0, 0, 3, 3, 7, 7, 40, 200]))      # (40, 200: beyond the pose rows a launch carries in its arguments)
     sc = make_scene(n, seed=88_000 + seed, log_scale_mean=ls, n_groups=n_groups)
     lo = float(rng.choice([0.004, 0.05, 0.5]))
     sc.opacities[:] = np.clip(sc.opacities, lo, min(1.0, lo * 20 + 0.01)).astype(np.float32)
@@ -43,6 +44,8 @@ def draw_case(seed: int) -> dict:
         sc.means *= np.float32(0.05)                                         # everything in a few tiles: long lists
     deg = int(rng.choice([-1, 0, 1, 2, 3, 3, 3]))
     W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
+    if rng.random() < 0.05:                                                  # a strip: one row or one column of tiles, thousands of pixels long
+        W, H = (int(rng.integers(1000, 4000)), int(rng.integers(1, 17))) if rng.random() < 0.5 else (int(rng.integers(1, 17)), int(rng.integers(1000, 3000)))
     poisoned = bool(rng.random() < 0.08)
     if rng.random() < 0.06:                                                  # now and then a large frame and a large scene
         W, H = int(rng.integers(640, 1921)), int(rng.integers(480, 1081))
@@ -63,7 +66,12 @@ def draw_case(seed: int) -> dict:
         eye = (radius * np.sin(yaw), elev, radius * np.cos(yaw))
         f = float(rng.uniform(0.4, 1.5)) * W
         cx, cy = W / 2.0 + float(rng.uniform(-0.2, 0.2)) * W, H / 2.0 + float(rng.uniform(-0.2, 0.2)) * H
-        cams.append(Camera(look_at_viewmat(eye), intrinsics(f, f * float(rng.uniform(0.8, 1.25)), cx, cy), W, H))
+        V = look_at_viewmat(eye)
+        if rng.random() < 0.1:                                               # odd cameras: fish-eye-short or telescope-long focal lengths, the
+            f = float(rng.choice([0.03, 0.1, 8.0, 40.0])) * max(W, H)        # principal point outside the image, a view matrix that is not quite a rotation
+            cx, cy = float(rng.uniform(-1.0, 2.0)) * W, float(rng.uniform(-1.0, 2.0)) * H
+            V = V.copy(); V[:3, :3] *= np.float32(rng.uniform(0.97, 1.03))
+        cams.append(Camera(V, intrinsics(f, f * float(rng.uniform(0.8, 1.25)), cx, cy), W, H))
     entry = "single" if n_views == 1 else str(rng.choice(["batch", "batch", "posed", "host"]))
     if n_groups == 0 and entry == "posed":
         entry = "batch"
