@@ -246,7 +246,8 @@ static void cam_from(const float viewmat[16], const float K[9], int W, int H, ca
 
 /* per-Gaussian projection result */
 typedef struct {
-    int32_t rx, ry;          /* 0,0 = culled */
+    int32_t rx, ry;          /* 0,0 = culled; saturated at 2147483520 (the largest float below 2^31) */
+    float rxf, ryf;          /* the radii as computed (integer-valued floats): what T3 takes its rectangle from */
     float mx, my, depth;
     float ca, cb, cc;        /* conic */
     float rgb[3];
@@ -351,7 +352,10 @@ static void project_one(const sas_oracle_scene *s, const cam_t *c, int64_t i, pr
     if (rx <= 0.0f && ry <= 0.0f) return;
     if (mx + rx <= 0.0f || mx - rx >= Wf || my + ry <= 0.0f || my - ry >= Hf) return;
 
-    o->rx = (int32_t)rx; o->ry = (int32_t)ry;
+    /* (a float beyond the int32 range is undefined behaviour in a C cast: absurd scales or a camera inside a Gaussian produce
+     * such radii; the HIP side saturates its parity hook the same way and, like here, takes the rectangle from the float) */
+    o->rx = (int32_t)fminf(rx, 2147483520.0f); o->ry = (int32_t)fminf(ry, 2147483520.0f);
+    o->rxf = rx; o->ryf = ry;
     o->mx = mx; o->my = my; o->depth = z;
     o->ca = ca; o->cb = cb; o->cc = ccn;
     o->opac = op;
@@ -374,7 +378,7 @@ static void project_one(const sas_oracle_scene *s, const cam_t *c, int64_t i, pr
 static inline void tile_rect(const proj_t *p, const cam_t *c, int *x0, int *x1, int *y0, int *y1)
 {
     const float ts = (float)OC_TILE;
-    float trx = (float)p->rx / ts, try_ = (float)p->ry / ts;
+    float trx = p->rxf / ts, try_ = p->ryf / ts;
     float tx = p->mx / ts, ty = p->my / ts;
     float fx0 = floorf(tx - trx), fx1 = ceilf(tx + trx);
     float fy0 = floorf(ty - try_), fy1 = ceilf(ty + try_);

@@ -53,7 +53,7 @@ def draw_case(seed: int) -> dict:
         sc = make_scene(n, seed=88_000 + seed, log_scale_mean=float(rng.uniform(np.log(0.004), np.log(0.03))), n_groups=n_groups)
     if poisoned:     # non-finite and absurd values in ~1 % of the Gaussians: both sides must cull or clamp them the same way, and the
         # device must not leave its buffers (the bounds-checked build counts)
-        bad_vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 0.0], np.float32)
+        bad_vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 0.0, 3e6, 1e12, -1.0], np.float32)
         for arr in (sc.means, sc.scales, sc.quats, sc.opacities, sc.sh):
             flat = arr.reshape(-1)
             k = max(1, flat.size // 100)
