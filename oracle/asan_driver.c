@@ -1,5 +1,5 @@
 /* Sanitizer leg of the CPU oracle (test infrastructure): renders a small seeded scene, including
- * ragged image sizes, group poses, culled and empty scenes, under -fsanitize=address,undefined.
+ * ragged image sizes, group poses, culled and empty scenes and poisoned scenes (NaN, Inf, absurd magnitudes), under -fsanitize=address,undefined.
  * Exit code 0 and no sanitizer report = pass.  Built by `make -C oracle asan`. */
 #include "sas_oracle.c"
 #include <stdio.h>
@@ -7,7 +7,7 @@
 static unsigned long long rs = 88172645463325252ull;
 static float frand(void) { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (float)((rs >> 11) * (1.0 / 9007199254740992.0)); }
 
-static int run(int n, int W, int H, int groups, int degree)
+static int run(int n, int W, int H, int groups, int degree, int poison)
 {
     float *means = malloc(sizeof(float) * 3 * (n + 1)), *quats = malloc(sizeof(float) * 4 * (n + 1));
     float *scales = malloc(sizeof(float) * 3 * (n + 1)), *op = malloc(sizeof(float) * (n + 1));
@@ -22,6 +22,19 @@ static int run(int n, int W, int H, int groups, int degree)
         op[i] = frand();
         for (int k = 0; k < 3 * kk; ++k) col[3 * kk * i + k] = frand() - 0.3f;
         gid[i] = (uint8_t)(i % 4);
+    }
+    if (poison) {   /* absurd inputs (NaN, Inf, 1e30, scales that give radii beyond int32): no cast, index or shift may leave its range */
+        const float bad[10] = {NAN, INFINITY, -INFINITY, 1e30f, -1e30f, 1e-30f, 0.0f, 3e6f, 1e12f, -1.0f};
+        for (int i = 0; i < n; i += 7) {
+            const float v = bad[(i / 7) % 10];
+            switch ((i / 70) % 5) {
+            case 0: means[3 * i + (i % 3)] = v; break;
+            case 1: scales[3 * i + (i % 3)] = v; break;
+            case 2: quats[4 * i + (i % 4)] = v; break;
+            case 3: op[i] = v; break;
+            default: col[3 * kk * i + (i % (3 * kk))] = v; break;
+            }
+        }
     }
     sas_oracle_scene s = {n, means, quats, scales, NULL, op, col, degree, groups ? gid : NULL, groups ? 4 : 0, groups ? Rt : NULL};
     float V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 3, 0, 0, 0, 1};
@@ -45,10 +58,12 @@ static int run(int n, int W, int H, int groups, int degree)
 int main(void)
 {
     int rc = 0;
-    rc |= run(3000, 97, 61, 0, 3);
-    rc |= run(500, 16, 16, 1, 2);
-    rc |= run(1, 1, 1, 0, 0);
-    rc |= run(0, 33, 20, 0, 3);
-    rc |= run(800, 40, 40, 1, -1);
+    rc |= run(3000, 97, 61, 0, 3, 0);
+    rc |= run(500, 16, 16, 1, 2, 0);
+    rc |= run(1, 1, 1, 0, 0, 0);
+    rc |= run(0, 33, 20, 0, 3, 0);
+    rc |= run(800, 40, 40, 1, -1, 0);
+    rc |= run(3000, 97, 61, 1, 3, 1);
+    rc |= run(1500, 50, 70, 0, -1, 1);
     return rc;
 }
