@@ -152,7 +152,7 @@ def test_sh2rgb_constant():
 
 
 def test_oracle_under_address_and_ub_sanitizers():
-    """CPU-only sanitizer leg: the oracle's allocations and indexing on ragged / empty / grouped scenes."""
+    """CPU-only sanitizer leg: the oracle's allocations, indexing and casts on ragged / empty / grouped / poisoned scenes."""
     import subprocess
     from pathlib import Path
     odir = Path(__file__).resolve().parent.parent / "oracle"
@@ -160,7 +160,7 @@ def test_oracle_under_address_and_ub_sanitizers():
     res = subprocess.run([str(odir / "_build" / "oracle_asan")], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr
-    assert res.stdout.count("intersections") == 5
+    assert res.stdout.count("intersections") == 7      # five ordinary scenes, two poisoned (NaN, Inf, absurd magnitudes: float-cast-overflow is checked)
 
 
 def test_contract_deviations_from_the_textbook_formulas_stay_far_below_the_parity_tolerance():
