@@ -13,7 +13,7 @@ bit for bit (the arithmetic contract); the seeded pytest cases fix 
              uint8 frames, a blocking frame with the complete sorted lists kept, and PIPELINED steps (3-6 steps enqueued without waiting -- single frames or batches, new group poses
              before every step, four frames in flight over the slot ring -- then one wait); depth fill on or off; nerfstudio's eval background or a drawn one
 
-    python tests/tools/oracle_fuzz.py [n_seeds] [first_seed]          (exit code 1 on the first difference; prints each case)
+    python tests/tools/oracle_fuzz.py [n_seeds] [first_seed] [poison-all]         (exit code 1 on the first difference; prints each case)
 
 Test infrastructure: lives under tests/ because it calls the oracle (the checker)."""
 import sys
@@ -30,7 +30,7 @@ from sim_a_splat_amd.synthetic import (NERFSTUDIO_EVAL_BACKGROUND as BG, Camera,
 KEYS = ("rgb", "alpha", "depth", "rgb8")
 
 
-def draw_case(seed: int) -> dict:
+def draw_case(seed: int, poison_all: bool = False) -> dict:
     rng = np.random.default_rng(77_000 + seed)
     n = int(rng.choice([1, 7, 50, 800, 6000, 30000, 120000], p=[0.04, 0.06, 0.1, 0.25, 0.25, 0.2, 0.1]))
     ls = float(rng.uniform(np.log(0.003), np.log(0.3)))
@@ -46,7 +46,7 @@ def draw_case(seed: int) -> dict:
     W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
     if rng.random() < 0.05:                                                  # a strip: one row or one column of tiles, thousands of pixels long
         W, H = (int(rng.integers(1000, 4000)), int(rng.integers(1, 17))) if rng.random() < 0.5 else (int(rng.integers(1, 17)), int(rng.integers(1000, 3000)))
-    poisoned = bool(rng.random() < 0.08)
+    poisoned = bool(rng.random() < 0.08) or poison_all
     if rng.random() < 0.06:                                                  # now and then a large frame and a large scene
         W, H = int(rng.integers(640, 1921)), int(rng.integers(480, 1081))
         n = int(rng.choice([120000, 500000, 1000000]))
@@ -204,10 +204,11 @@ def main(argv) -> int:
     from sim_a_splat_amd.rasterizer import Rasterizer
     n_seeds = int(argv[1]) if len(argv) > 1 else 60
     first = int(argv[2]) if len(argv) > 2 else 0
+    poison_all = len(argv) > 3 and argv[3] == "poison-all"
     r = Rasterizer(0)
     bad = 0
     for seed in range(first, first + n_seeds):
-        c = draw_case(seed)
+        c = draw_case(seed, poison_all)
         diffs = run_case(r, c)
         st = r.stats()
         print(describe(c), f"max_list={st['max_tile_len']} ->", "bit-equal" if not diffs else "DIFFERENT: " + "; ".join(diffs), flush=True)
