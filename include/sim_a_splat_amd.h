@@ -92,6 +92,10 @@ int sas_destroy(sas_ctx *ctx);
  *              sh_degree <  0: [n,3] final RGB in 0..1 (Door B: SH2RGB already applied)
  *   group_id   [n] uint8 splat-group index, or NULL (single static group)
  *   n_groups   number of groups (<= 256); poses start as identity
+ * Values are taken as they are (no validation pass over the scene): every float32 is defined input.  A Gaussian whose projection
+ * is not finite is culled; NaN / Inf / out-of-range opacities and colours render exactly as the oracle renders them (DESIGN.md 3,
+ * "Inputs outside the reference's range"; colours leave the projection clamped to +-FLT_MAX); no input makes a kernel leave its
+ * buffers (tests/tools/oracle_fuzz.py poisons scenes on the bounds-checked build).
  */
 int sas_scene_upload(sas_ctx *ctx, int64_t n, const float *means, const float *quats, const float *scales,
                      const float *cov6, const float *opacities, const float *colors, int sh_degree,
