@@ -601,6 +601,9 @@ DEV BlendLds blend_lds(unsigned char *raw)
 // their own queues in lockstep, front to back (a group that runs out reads the sentinel record,
 // which no pixel accepts).  Returns true when every pixel of the tile has terminated (uniform over
 // the workgroup).  `slot_at(i)` gives the storage slot of entry i.
+#ifndef SAS_TUNE_LATE_COLOUR
+#define SAS_TUNE_LATE_COLOUR 0
+#endif
 template <bool FAST_EXP, typename SlotAt>
 DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const PixConst pc, int count, SlotAt slot_at,
                      const BlendLds &L, PixState &p, bool &wdone, unsigned long long &ph_lap_)
@@ -631,9 +634,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
     if (count > 0) fetch(0);
     if (tid == 0) {   // sentinel record: opacity 0 (built here from opaque registers: hipcc otherwise keeps the
         // constant vectors alive across the tile's rounds and spills them)
-        const float z0 = vgpr_const(0u), m1 = vgpr_const(0xbf800000u);
+        const float z0 = vgpr_const(0u);
         L.q0[256] = make_float4(z0, z0, z0, z0);
-        L.q1[256] = make_float4(z0, z0, m1, z0);
+        L.q1[256] = make_float4(z0, z0, z0, z0);
         L.q2[256] = make_float4(z0, z0, z0, z0);
     }
     const float X0 = (float)(tx * SAS_TILE) + kTileCentre, Y0 = (float)(ty * SAS_TILE) + kTileCentre;   // the polynomial's origin: the tile's centre
@@ -691,8 +694,9 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
         {
             const float u = ra.x - X0, v = ra.y - Y0;
             const float A = ra.z, B = ra.w, C = rb.x;
-            L.q0[tid] = make_float4(u, v, 0.0f, 0.5f * A);
-            L.q1[tid] = make_float4(0.5f * C, B, rb.z, rb.y);    // .z threshold, .w opacity
+            // (what a trip reads is packed: q0 whole, q1's first half -- a 16-byte and an 8-byte LDS read per entry, six registers)
+            L.q0[tid] = make_float4(u, v, 0.5f * A, B);
+            L.q1[tid] = make_float4(0.5f * C, rb.y, 0.0f, 0.0f);   // .y opacity
             L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);     // colour, depth
             L.mask[tid] = ment;
         }
@@ -751,7 +755,11 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
             // Two queue entries per trip: their record loads, sigmas and exponentials are independent
             // (one wave alone cannot hide the two dependent LDS round trips of an entry); only the
             // transmittance chain is sequential.  A queue of odd length ends on the sentinel.
-            struct Trip { float4 K0, H0, K1, H1, C0, C1; };
+#if SAS_TUNE_LATE_COLOUR
+            struct Trip { float4 K0, K1; float2 H0, H1; unsigned o0, o1; };
+#else
+            struct Trip { float4 K0, K1, C0, C1; float2 H0, H1; };
+#endif
             auto load_trip = [&](Trip &t, int k, unsigned pair) {   // pair = queue entries k, k + 1
                 unsigned off0 = pair & 0xffffu, off1 = pair >> 16;
 #ifdef SAS_TUNE_STATS
@@ -762,17 +770,21 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #endif
                 if (!SAS_IN(k + 1, 256, 203) || !SAS_IN(off0 >> 4, kStage, 204) || !SAS_IN(off1 >> 4, kStage, 205)) off0 = off1 = 256u << 4;
                 t.K0 = *reinterpret_cast<const float4 *>(q0b + off0);
-                t.H0 = *reinterpret_cast<const float4 *>(q1b + off0);
+                t.H0 = *reinterpret_cast<const float2 *>(q1b + off0);
                 t.K1 = *reinterpret_cast<const float4 *>(q0b + off1);
-                t.H1 = *reinterpret_cast<const float4 *>(q1b + off1);
+                t.H1 = *reinterpret_cast<const float2 *>(q1b + off1);
+#if SAS_TUNE_LATE_COLOUR
+                t.o0 = off0; t.o1 = off1;   // (experiment: colour and depth are fetched when the alphas are known -- 8 registers fewer at the trip's peak)
+#else
                 t.C0 = *reinterpret_cast<const float4 *>(q2b + off0);   // colour, depth
                 t.C1 = *reinterpret_cast<const float4 *>(q2b + off1);
+#endif
             };
             // returns true when every pixel of the wave has terminated
             auto composite_trip = [&](const Trip &t) -> bool {
                 const float dx0 = t.K0.x - p.x, dy0 = t.K0.y - pc.y, dx1 = t.K1.x - p.x, dy1 = t.K1.y - pc.y;
-                const float sg0 = fma_(dx0, fma_(t.H0.y, dy0, t.K0.w * dx0), (t.H0.x * dy0) * dy0);
-                const float sg1 = fma_(dx1, fma_(t.H1.y, dy1, t.K1.w * dx1), (t.H1.x * dy1) * dy1);
+                const float sg0 = fma_(dx0, fma_(t.K0.w, dy0, t.K0.z * dx0), (t.H0.x * dy0) * dy0);
+                const float sg1 = fma_(dx1, fma_(t.K1.w, dy1, t.K1.z * dx1), (t.H1.x * dy1) * dy1);
                 // Every decision below is a per-lane select on a value, not a wave mask combined on the
                 // scalar unit (which the CU's four SIMDs share: a scalar instruction costs as much issue time
                 // as a vector one).  A lane the splat does not reach has a large sigma: the contract's clamp
@@ -782,8 +794,8 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 float E0, E1;
                 if (FAST_EXP) { E0 = __expf(fmaxf(-sg0, -86.0f)); E1 = __expf(fmaxf(-sg1, -86.0f)); }
                 else { E0 = c_expf_neg(fmaxf(-sg0, -86.0f), sE5); E1 = c_expf_neg(fmaxf(-sg1, -86.0f), sE5); }
-                const float al0 = fminf(kMaxAlpha, t.H0.w * E0);
-                const float al1 = fminf(kMaxAlpha, t.H1.w * E1);
+                const float al0 = fminf(kMaxAlpha, t.H0.y * E0);
+                const float al1 = fminf(kMaxAlpha, t.H1.y * E1);
                 // weight w = alpha T (0 when the splat is skipped), next T = T - w, for both entries as if no
                 // pixel terminated; T only falls, so one test of the last T tells whether any did
                 const float w0 = (al0 < kAlphaThr) ? 0.0f : al0 * p.T;
@@ -805,10 +817,19 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
                 p.T = Tn;
                 // lanes that do not composite add with weight +0: fmaf(c, 0, x) == x for the finite
                 // colours and depths of the path
+#if SAS_TUNE_LATE_COLOUR
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 lc0 = *reinterpret_cast<const float4 *>(q2b + t.o0), lc1 = *reinterpret_cast<const float4 *>(q2b + t.o1);
+                p.r = fma_(lc1.x, vis1, fma_(lc0.x, vis0, p.r));
+                p.g = fma_(lc1.y, vis1, fma_(lc0.y, vis0, p.g));
+                p.b = fma_(lc1.z, vis1, fma_(lc0.z, vis0, p.b));
+                p.d = fma_(lc1.w, vis1, fma_(lc0.w, vis0, p.d));
+#else
                 p.r = fma_(t.C1.x, vis1, fma_(t.C0.x, vis0, p.r));
                 p.g = fma_(t.C1.y, vis1, fma_(t.C0.y, vis0, p.g));
                 p.b = fma_(t.C1.z, vis1, fma_(t.C0.z, vis0, p.b));
                 p.d = fma_(t.C1.w, vis1, fma_(t.C0.w, vis0, p.d));
+#endif
 #ifdef SAS_TUNE_STATS
                 {
                     const unsigned long long m0 = __ballot(vis0 > 0.0f), m1 = __ballot(vis1 > 0.0f);
@@ -897,9 +918,9 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
     };
     if (count > 0) fetch(0);
     if (tid == 0) {
-        const float z0 = vgpr_const(0u), m1 = vgpr_const(0xbf800000u);
+        const float z0 = vgpr_const(0u);
         L.q0[256] = make_float4(z0, z0, z0, z0);
-        L.q1[256] = make_float4(z0, z0, m1, z0);
+        L.q1[256] = make_float4(z0, z0, z0, z0);
         L.q2[256] = make_float4(z0, z0, z0, z0);
     }
     const float X0 = (float)(tx * SAS_TILE) + kTileCentre, Y0 = (float)(ty * SAS_TILE) + kTileCentre;   // the polynomial's origin: the tile's centre
@@ -920,8 +941,8 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
         {   // (contract T6: see blend_range)
             const float u = ra.x - X0, v = ra.y - Y0;
             const float A = ra.z, B = ra.w, C = rb.x;
-            L.q0[tid] = make_float4(u, v, 0.0f, 0.5f * A);
-            L.q1[tid] = make_float4(0.5f * C, B, rb.z, rb.y);
+            L.q0[tid] = make_float4(u, v, 0.5f * A, B);              // (packed as in blend_range: q0 whole, q1's first half)
+            L.q1[tid] = make_float4(0.5f * C, rb.y, 0.0f, 0.0f);
             L.q2[tid] = make_float4(rc.x, rc.y, rc.z, rb.w);
             L.mask[tid] = ment;
         }
@@ -967,14 +988,14 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
                 do {
                     if (!SAS_IN(off >> 4, kStage, 233)) off = 256u << 4;
                     const float4 K = *reinterpret_cast<const float4 *>(q0b + off);
-                    const float4 H = *reinterpret_cast<const float4 *>(q1b + off);
+                    const float2 H = *reinterpret_cast<const float2 *>(q1b + off);
                     const float4 C = *reinterpret_cast<const float4 *>(q2b + off);
                     k += 4;
                     off = wq[k + e];   // next trip's entry, one trip ahead
                     const float dxq = K.x - p.x, dyq = K.y - pc.y;
-                    const float sg = fma_(dxq, fma_(H.y, dyq, K.w * dxq), (H.x * dyq) * dyq);
+                    const float sg = fma_(dxq, fma_(K.w, dyq, K.z * dxq), (H.x * dyq) * dyq);
                     const float E = FAST_EXP ? __expf(fmaxf(-sg, -86.0f)) : c_expf_neg(fmaxf(-sg, -86.0f), sE5);
-                    const float al = fminf(kMaxAlpha, H.w * E);
+                    const float al = fminf(kMaxAlpha, H.y * E);
                     // A skipped splat weighs 0: decided HERE, once per lane for its own entry, so that the chain below is one
                     // multiply (its operand the quad broadcast of entry j's alpha: v_mul_f32_dpp) and one subtraction per
                     // entry instead of broadcast + compare + multiply + select (0 * T == +0 for the finite T of the path:
@@ -1346,10 +1367,14 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         __syncthreads();
         unsigned long long kk[NK];
         unsigned mn = ~0u, mx = 0u;
+        // (the list's base, opaque per phase: hipcc otherwise forms this thread's key address once per tile and parks the 64-bit
+        // value in scratch between the phases that read keys)
+        const unsigned long long *g1 = g;
+        asm volatile("" : "+s"(g1));
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
             const int i = u * kLazyThreads + tid;
-            kk[u] = (i < n) ? g[i] : ~0ull;
+            kk[u] = (i < n) ? g1[i] : ~0ull;
             if (i < n) { mn = min(mn, hi32(kk[u])); mx = max(mx, hi32(kk[u])); }
         }
 #pragma unroll
@@ -1425,12 +1450,14 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         const bool cached = n <= kKeyCache;   // (uniform)
         unsigned mn = ~0u, mx = 0u;
         if (cached) {
+            const unsigned long long *g2 = g;
+            asm volatile("" : "+s"(g2));
             for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
                 unsigned long long kk[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * kLazyThreads + tid;
-                    kk[u] = (i < n) ? g[i] : 0ull;
+                    kk[u] = (i < n) ? g2[i] : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1563,12 +1590,14 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                     }
                 }
             } else if (!partitioned) {
+                const unsigned long long *g3 = g;
+                asm volatile("" : "+s"(g3));
                 for (int i0 = 0; i0 < n; i0 += kLazyThreads * U) {
                     unsigned long long kk[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int i = i0 + u * kLazyThreads + tid;
-                        kk[u] = (i < n) ? g[i] : ~0ull;
+                        kk[u] = (i < n) ? g3[i] : ~0ull;
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
