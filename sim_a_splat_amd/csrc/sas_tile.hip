@@ -45,6 +45,22 @@ DEV bool key_greater(unsigned long long a, unsigned long long b, const int *perm
 // Ranks come from wave ballots, so equal digits keep their order (a returning LDS atomic would
 // not).  Between barriers the keys live in registers, which makes one buffer enough.
 // Afterwards runs of identical high words are ordered by perm[low word].
+// AND / OR of one WAVE-UNIFORM flag per wave over the workgroup's four waves, with ONE barrier.  (hipcc's __syncthreads_and / _or is
+// an LDS word, a write, an atomic by one lane per wave, a read -- and THREE barriers; the compositing loop runs one per batch of
+// 256 entries.)  Two flag rows used alternately (`phase`, uniform, counted by the caller): a wave that is already at the next
+// reduction writes the other row, so no barrier is needed between consecutive reductions.
+template <bool AND>
+DEV bool wg_reduce_wave_flags(bool wave_flag, unsigned &phase)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_flags[8];
+    unsigned *row = s_flags + 4u * (phase & 1u);
+    ++phase;
+    if ((threadIdx.x & 63u) == 0u) row[threadIdx.x >> 6] = wave_flag ? 1u : 0u;
+    __syncthreads();
+    const uint4 v = *reinterpret_cast<const uint4 *>(row);
+    return AND ? ((v.x & v.y & v.z & v.w) != 0u) : ((v.x | v.y | v.z | v.w) != 0u);
+}
+
 template <int W, int NB>
 DEV void lds_radix_sort(unsigned long long *buf, int m, unsigned span, const int *perm, unsigned *cnt /*[W][256]*/,
                         unsigned *dbase /*[256]*/, unsigned *wsum /*[4]*/)
@@ -606,7 +622,7 @@ DEV BlendLds blend_lds(unsigned char *raw)
 #endif
 template <bool FAST_EXP, typename SlotAt>
 DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const PixConst pc, int count, SlotAt slot_at,
-                     const BlendLds &L, PixState &p, bool &wdone, unsigned long long &ph_lap_)
+                     const BlendLds &L, PixState &p, bool &wdone, unsigned long long &ph_lap_, unsigned &sync_phase)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
@@ -654,7 +670,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #endif
     for (int at = 0; at < count; at += 256) {
         // the previous batch is fully consumed; leave once every wave has terminated
-        const bool every_done = __syncthreads_and(wdone);
+        const bool every_done = wg_reduce_wave_flags<true>(wdone, sync_phase);   // (wdone is wave-uniform)
         PH_LAP(11);
 #ifdef SAS_TUNE_STATS
         if (t_loop_end) DBG_ADD(6, clock64() - t_loop_end);   // [6] cycles waves waited for the slowest wave of a batch
@@ -878,7 +894,7 @@ DEV bool blend_range(const SasFrame &f, long long n_gauss, int tx, int ty, const
 #endif
         }
     }
-    if (!all_done) all_done = __syncthreads_and(wdone);   // also fences the staging buffers
+    if (!all_done) all_done = wg_reduce_wave_flags<true>(wdone, sync_phase);   // also fences the staging buffers
     return all_done;
 }
 
@@ -896,7 +912,7 @@ DEV float quad_bcast(float v)
 }
 template <bool FAST_EXP, typename SlotAt>
 DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, int qd, const PixConst pc, int count, SlotAt slot_at,
-                          const BlendLds &L, PixState &p, bool &wdone)
+                          const BlendLds &L, PixState &p, bool &wdone, unsigned &sync_phase)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
@@ -932,7 +948,7 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
     bool all_done = false;
     for (int at = 0; at < count; at += 256) {
         const unsigned long long t_b0 = PH_T();
-        const bool every_done = __syncthreads_and(wdone);
+        const bool every_done = wg_reduce_wave_flags<true>(wdone, sync_phase);
         if (every_done) { all_done = true; break; }
         const unsigned long long t_b1 = PH_T();
         PH_ADD(4, t_b1 - t_b0);
@@ -1047,7 +1063,7 @@ DEV bool blend_range_quad(const SasFrame &f, long long n_gauss, int tx, int ty, 
             wdone = __all(pix_dead(p));
         }
     }
-    if (!all_done) all_done = __syncthreads_and(wdone);
+    if (!all_done) all_done = wg_reduce_wave_flags<true>(wdone, sync_phase);
     return all_done;
 }
 
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long lon
     const SasOutputs &o = P.out;
     const BlendLds L = blend_lds(s_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned sync_phase = 0u;
     for (int oi = range[0] + (int)blockIdx.x; oi < range[1]; oi += (int)gridDim.x) {
         const int tile = tl[oi];
         const int tx = tile % c.tw, ty = tile / c.tw;
@@ -1164,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_blend(SasParams P, SasFrame f, long lon
         const int *ids = f.sorted_ids + beg;
         unsigned long long ph_lap_ = 0ull;
         blend_range<FAST_EXP>(f, n_gauss, tx, ty, pix_const(ox, oy), (int)(end - beg),
-                              [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone, ph_lap_);
+                              [&](int i) { return (long long)(unsigned)ids[i]; }, L, p, wdone, ph_lap_, sync_phase);
         unsigned packed;
         const float ED = write_pixel(o, p, inside, ix, iy, c.W, packed);
         if (o.rgb8_host) store_rows_to_host<16>(o.rgb8_host, c.W, tx * SAS_TILE, ty * SAS_TILE, ox, oy, true, packed, s_raw);
@@ -1333,12 +1350,13 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
 #else
     unsigned long long ph_lap_ = 0ull;
 #endif
+    unsigned sync_phase = 0u;   // (wg_reduce_wave_flags)
     // composite `count` ordered entries in this kernel's layout
     auto blend = [&](int count, auto slot_at) -> bool {
         const unsigned long long t_b = PH_T();
         bool r;
-        if constexpr (QUAD) r = blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone);
-        else r = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone, ph_lap_);
+        if constexpr (QUAD) r = blend_range_quad<FAST_EXP>(f, n_gauss, tx, ty, qd, pc, count, slot_at, L, p, wdone, sync_phase);
+        else r = blend_range<FAST_EXP>(f, n_gauss, tx, ty, pc, count, slot_at, L, p, wdone, ph_lap_, sync_phase);
         PH_ADD(1, PH_T() - t_b);
         return r;
     };
@@ -1412,7 +1430,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             __syncthreads();
             for (int w = 0; w < wv; ++w) incl += s_wsum[w];
             s_cur[tid] = incl - hv;   // start of bucket tid
-            const bool big = __syncthreads_or(hv > (unsigned)kRankMax);
+            const bool big = wg_reduce_wave_flags<false>(__any(hv > (unsigned)kRankMax), sync_phase);
 #pragma unroll
             for (int u = 0; u < NK; ++u) {
                 if (u * kLazyThreads + tid < n) {
@@ -1577,7 +1595,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             } else if (mine) {
                 s_cur[tid] = my_incl;   // END of bucket t inside the chunk (what the collect pass leaves): b0 is the first non-empty bucket of the scan
             }
-            const bool big = __syncthreads_or(mine && my_hv > (unsigned)kRankMax);
+            const bool big = wg_reduce_wave_flags<false>(__any(mine && my_hv > (unsigned)kRankMax), sync_phase);
             const unsigned long long t_c = PH_T();
             if (!partitioned && cached && b_next == 0) {
                 // first round of a cached list: the keys are in LDS
