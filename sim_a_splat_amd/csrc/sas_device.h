@@ -54,6 +54,56 @@ DEV float4 nt_load(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// ---- wave64 reductions and scan on the DPP network --------------------------------------------------------------------------------
+// hipcc lowers __shfl_xor / __shfl_up to ds_bpermute_b32: a trip through the LDS crossbar per step, six DEPENDENT trips per reduction
+// (~0.3 us on the chain of a workgroup that does nothing else meanwhile).  The same steps as DPP operand modifiers cost a few
+// issue slots each: butterflies inside the quads and rows (quad_perm, row_half_mirror, row_mirror: every lane of a row then holds
+// its row's value), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's value, read by
+// v_readlane.  Every lane of the wave must be active (the call sites are wave-uniform).  Result: uniform.
+template <int CTRL, int ROW_MASK>
+DEV int dpp_take(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+template <typename Op>
+DEV int wave_reduce_i32(int v, int identity, Op op)
+{
+    v = op(v, dpp_take<0xB1, 0xf>(identity, v));    // quad_perm [1,0,3,2]
+    v = op(v, dpp_take<0x4E, 0xf>(identity, v));    // quad_perm [2,3,0,1]
+    v = op(v, dpp_take<0x141, 0xf>(identity, v));   // row_half_mirror
+    v = op(v, dpp_take<0x140, 0xf>(identity, v));   // row_mirror
+    v = op(v, dpp_take<0x142, 0xa>(identity, v));   // row_bcast:15 -> rows 1, 3
+    v = op(v, dpp_take<0x143, 0xc>(identity, v));   // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+DEV int wave_min_i32(int v) { return wave_reduce_i32(v, 0x7fffffff, [](int a, int b) { return a < b ? a : b; }); }
+DEV int wave_max_i32(int v) { return wave_reduce_i32(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }); }
+DEV int wave_sum_i32(int v) { return wave_reduce_i32(v, 0, [](int a, int b) { return a + b; }); }
+DEV unsigned wave_min_u32(unsigned v)
+{
+    return (unsigned)wave_reduce_i32((int)v, -1, [](int a, int b) { return (int)((unsigned)a < (unsigned)b ? (unsigned)a : (unsigned)b); });
+}
+DEV unsigned wave_max_u32(unsigned v)
+{
+    return (unsigned)wave_reduce_i32((int)v, 0, [](int a, int b) { return (int)((unsigned)a > (unsigned)b ? (unsigned)a : (unsigned)b); });
+}
+// inclusive prefix sum over the wave's 64 lanes (row_shr 1, 2, 3 on the input, then 4 and 8 with bank masks, then the two row
+// broadcasts: the scan of the GCN3 cross-lane note)
+DEV unsigned wave_inclusive_sum_u32(unsigned x)
+{
+    const int v0 = (int)x;
+    int v = v0 + __builtin_amdgcn_update_dpp(0, v0, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v0, 0x112, 0xf, 0xf, false);              // row_shr:2 (of the input)
+    v += __builtin_amdgcn_update_dpp(0, v0, 0x113, 0xf, 0xf, false);              // row_shr:3 (of the input)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);               // row_shr:4, banks 1-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);               // row_shr:8, banks 2-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);               // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);               // row_bcast:31 -> rows 2, 3
+    return (unsigned)v;
+}
+
+// lane `src` (uniform) of a register: v_readlane_b32 (hipcc's __shfl(v, src) is a ds_bpermute_b32 round trip even when src is uniform)
+DEV int lane_get(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+DEV unsigned lane_get(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
+DEV float lane_get(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+
 // ---- contract logarithm (mirrors sas_oracle_logf; the contract exponential lives with its only
 //      user, the compositing loop: c_expf_neg in sas_tile.hip) ------------------------------------
 DEV float c_logf(float x)

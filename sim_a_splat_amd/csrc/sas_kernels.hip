@@ -238,9 +238,9 @@ DEV void for_each_tile(bool active, int x0, int x1, int y0, int y1, int tw, unsi
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
-        const int bw = __shfl(w, src), ba = __shfl(area, src);
-        const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
+        const int bx0 = lane_get(x0, src), by0 = lane_get(y0, src);   // (src is uniform: v_readlane)
+        const int bw = lane_get(w, src), ba = lane_get(area, src);
+        const unsigned b0 = lane_get(v0, src), b1 = lane_get(v1, src);
 #pragma unroll 1
         for (int i = lane; i < ba; i += 64) emit((by0 + i / bw) * tw + bx0 + i % bw, b0, b1);
     }
@@ -271,13 +271,8 @@ DEV Window wg_window(bool part, int x0, int x1, int y0, int y1, int *s_win)
 {
     int mnx = part ? x0 : 0x7fffffff, mny = part ? y0 : 0x7fffffff;
     int mxx = part ? x1 : 0, mxy = part ? y1 : 0;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, d));
-        mny = min(mny, __shfl_xor(mny, d));
-        mxx = max(mxx, __shfl_xor(mxx, d));
-        mxy = max(mxy, __shfl_xor(mxy, d));
-    }
+    mnx = wave_min_i32(mnx); mny = wave_min_i32(mny);   // (DPP steps: sas_device.h)
+    mxx = wave_max_i32(mxx); mxy = wave_max_i32(mxy);
     if (threadIdx.x == 0) { s_win[0] = 0x7fffffff; s_win[1] = 0x7fffffff; s_win[2] = 0; s_win[3] = 0; }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
@@ -302,13 +297,8 @@ DEV Window wg_window_zeroed(bool part, int x0, int x1, int y0, int y1, int *s_wi
 {
     int mnx = part ? x0 : 0x7fffffff, mny = part ? y0 : 0x7fffffff;
     int mxx = part ? x1 : 0, mxy = part ? y1 : 0;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, d));
-        mny = min(mny, __shfl_xor(mny, d));
-        mxx = max(mxx, __shfl_xor(mxx, d));
-        mxy = max(mxy, __shfl_xor(mxy, d));
-    }
+    mnx = wave_min_i32(mnx); mny = wave_min_i32(mny);   // (DPP steps: sas_device.h)
+    mxx = wave_max_i32(mxx); mxy = wave_max_i32(mxy);
     if ((threadIdx.x & 63) == 0) *reinterpret_cast<int4 *>(s_win16 + 4 * (threadIdx.x >> 6)) = make_int4(mnx, mny, mxx, mxy);
     static_assert(kHistBins == 2048, "eight bins per thread");
     reinterpret_cast<int4 *>(s_hist)[threadIdx.x] = make_int4(0, 0, 0, 0);
@@ -475,11 +465,11 @@ DEV void for_each_reached_tile(bool active, bool cull, const CullGeom &q, float 
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src);
-        const int bw = __shfl(w, src), ba = __shfl(area, src);
-        const unsigned b0 = __shfl(v0, src), b1 = __shfl(v1, src);
-        const CullGeom o{__shfl(q.mx, src), __shfl(q.my, src), __shfl(q.ha, src), __shfl(q.b, src),
-                         __shfl(q.hc, src), __shfl(q.nba, src), __shfl(q.nbc, src), __shfl(q.lim, src)};
+        const int bx0 = lane_get(x0, src), by0 = lane_get(y0, src);   // (src is uniform: v_readlane)
+        const int bw = lane_get(w, src), ba = lane_get(area, src);
+        const unsigned b0 = lane_get(v0, src), b1 = lane_get(v1, src);
+        const CullGeom o{lane_get(q.mx, src), lane_get(q.my, src), lane_get(q.ha, src), lane_get(q.b, src),
+                         lane_get(q.hc, src), lane_get(q.nba, src), lane_get(q.nbc, src), lane_get(q.lim, src)};
 #pragma unroll 1
         for (int i = lane; i < ba; i += 64) {
             const int ty = by0 + i / bw, tx = bx0 + i % bw;
@@ -585,8 +575,7 @@ DEV void count_tiles(const SasFrame &f, int tw, int tile_px, const ViewGeom &g, 
     int a16 = 0;
     if (f.wg_isect16) {   // (uniform) 8-pixel binning, culled lists: the frame still reports the intersections with the contract's 16-pixel tiles
         a16 = !vis ? 0 : tile_px == 8 ? (((x1 + 1) >> 1) - (x0 >> 1)) * (((y1 + 1) >> 1) - (y0 >> 1)) : rect_area;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) a16 += __shfl_xor(a16, d);
+        a16 = wave_sum_i32(a16);
     }
     // HAND-OFF RULE (projection workgroups -> the tail, possibly on another XCD, whose L2 is not coherent with this one):
     // everything the tail reads from other workgroups must be written by an AGENT-scope atomic (performed where all XCDs

@@ -1395,8 +1395,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             kk[u] = (i < n) ? g1[i] : ~0ull;
             if (i < n) { mn = min(mn, hi32(kk[u])); mx = max(mx, hi32(kk[u])); }
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+        mn = wave_min_u32(mn); mx = wave_max_u32(mx);   // (DPP steps: sas_device.h)
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
         const unsigned dmin = s_mn, span = s_mx - s_mn;
@@ -1420,12 +1419,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
         __syncthreads();
         {
             const unsigned hv = s_hist[tid];
-            unsigned incl = hv;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
+            unsigned incl = wave_inclusive_sum_u32(hv);
             if (lane == 63) s_wsum[wv] = incl;
             __syncthreads();
             for (int w = 0; w < wv; ++w) incl += s_wsum[w];
@@ -1496,8 +1490,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
                     if (i0 + u * kLazyThreads + tid < n) { mn = min(mn, dd[u]); mx = max(mx, dd[u]); }
             }
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, d)); mx = max(mx, (unsigned)__shfl_xor((int)mx, d)); }
+        mn = wave_min_u32(mn); mx = wave_max_u32(mx);   // (DPP steps: sas_device.h)
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
         PH_LAP(1);
@@ -1536,12 +1529,7 @@ DEV void tile_lazy_body(const SasParams &P, const SasFrame &f, long long n_gauss
             unsigned my_hv, my_incl;
             {
                 const unsigned hv = (tid >= b_next) ? s_hist[tid] : 0u;
-                unsigned incl = hv;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const unsigned o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
-                }
+                unsigned incl = wave_inclusive_sum_u32(hv);
                 if (lane == 63) s_wsum[wv] = incl;
                 __syncthreads();
                 for (int w = 0; w < wv; ++w) incl += s_wsum[w];        // inclusive count of buckets b_next..tid
