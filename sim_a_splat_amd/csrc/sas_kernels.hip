@@ -706,13 +706,8 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
 #endif
         }
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        total += __shfl_xor(total, d);
-        maxlen = max(maxlen, __shfl_xor(maxlen, d));
-        nvis += __shfl_xor(nvis, d);
-        n16 += __shfl_xor(n16, d);
-    }
+    total = wave_sum_i32(total); maxlen = wave_max_i32(maxlen);   // (DPP steps: sas_device.h)
+    nvis = wave_sum_i32(nvis); n16 = wave_sum_i32(n16);
     if (lane == 0) { s_w[wv] = total; s_w[4 + wv] = maxlen; }
     if (tid == 0) { s_w[8] = nvis; s_w[12] = n16; }
     __syncthreads();
@@ -723,12 +718,9 @@ DEV void scan_tail_single(const SasFrame *fp, int *lds, unsigned pl_wg_, unsigne
     for (int half = 0; half < 2; ++half) {
         const int idx = 256 * half + tid;
         const int v = s_bins[idx];
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const int o = __shfl_up(incl, d, 32);
-            if ((lane & 31) >= d) incl += o;
-        }
+        // (the scan over the wave's 64 lanes, less the lower half's total in the upper half: two scans of 32 lanes)
+        const int incl64 = (int)wave_inclusive_sum_u32((unsigned)v);
+        const int incl = lane < 32 ? incl64 : incl64 - lane_get(incl64, 31);
         my_incl[half] = incl;
         my_v[half] = v;
         if ((lane & 31) == 31) s_ctot[idx >> 5] = incl;

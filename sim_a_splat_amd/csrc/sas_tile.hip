@@ -1145,10 +1145,9 @@ DEV void store_rows_to_host(uint8_t *host, int W, int X0, int Y0, int ox, int oy
 DEV void store_tile_max(const SasFrame &f, int tile, float ED, unsigned *s_wmax)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float maxed = ED;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) maxed = fmaxf(maxed, __shfl_xor(maxed, d));
-    if (lane == 0) s_wmax[wv] = __float_as_uint(maxed);
+    // (expected depths are >= 0: their order is the order of their bit patterns, as the reduction over waves and tiles already takes it)
+    const unsigned maxed = wave_max_u32(__float_as_uint(ED));
+    if (lane == 0) s_wmax[wv] = maxed;
     __syncthreads();
     if (tid == 0) f.tile_max[tile] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     __syncthreads();
