@@ -48,6 +48,13 @@ def lib() -> ctypes.CDLL:
         raise SasError(
             f"{LIB_PATH} is missing: build it with `python -m sim_a_splat_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback for the render path.")
+    # ONE HIP runtime per process: the library is handed torch's device pointers and streams, so it has to resolve libamdhip64 to the
+    # copy torch has loaded.  Loaded BEFORE torch it binds the system copy instead, and sas_create then finds no device
+    # (SAS_ERR_NO_DEVICE) once torch has brought its own -- so torch comes first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:   # a C / ctypes consumer without torch: the system runtime is the only one
+        pass
     L = ctypes.CDLL(str(LIB_PATH))
     vp, ci, cu, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int64
     L.sas_create.argtypes = [ci, ctypes.POINTER(vp)]
